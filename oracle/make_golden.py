@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Pin the CPU oracle against the compiled reference runtime and (re)generate
+the committed fixtures under tests/golden/.
+
+TEST INFRASTRUCTURE.  Runs only in the build container (needs /root/reference
+to build oracle/_ref/libgmref.so via `make -C oracle ref`).  Nothing here is
+imported by the product, the GPU tests, smoke() or bench.py; those read the
+.npz / .json / .bin fixtures this script wrote.
+
+  python oracle/make_golden.py            # pin + rewrite fixtures
+  python oracle/make_golden.py --check    # pin only, do not rewrite
+
+What is pinned (oracle function  <-  reference code actually executed):
+  gmo_drand48                 <- glibc srand48/drand48 (what graph_gen.cc calls)
+  gmo_create_rmat_graph       <- create_RMAT_graph            (graph_gen.cc:159-287)
+  gmo_semi_sort / gmo_make_reverse_edges
+                              <- gm_graph::do_semi_sort / make_reverse_edges (gm_graph.cc)
+  gmo_get_edge_idx_for_src_dest <- gm_graph::get_edge_idx_for_src_dest (gm_graph.cc:589-633)
+  gmo_store_binary/load_binary <- gm_graph::store_binary / load_binary
+  gmo_pagerank                <- plain emission run on the reference runtime (ref_harness.cc)
+  gmo_hop_dist, gmo_bfs_queue <- emission on the reference runtime AND gm_bfs_template levels
+  gmo_triangle_counting(+merge) <- emission with gm_graph::is_neighbor
+"""
+import argparse
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, HERE)
+import pyoracle as po  # noqa: E402
+
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+INT_MAX = 2147483647
+
+
+def ref_lib():
+    subprocess.check_call(["make", "-C", HERE, "-j8", "ref"], stdout=subprocess.DEVNULL)
+    R = C.CDLL(os.path.join(HERE, "_ref", "libgmref.so"))
+    R.ref_drand48_stream.argtypes = [C.c_long, C.c_int, f64p]
+    R.ref_rmat_csr.argtypes = [C.c_int32, C.c_int32, C.c_long, C.c_double, C.c_double, C.c_double, C.c_int, i32p, i32p]
+    R.ref_prepare.argtypes = [C.c_int32, C.c_int32, i32p, i32p, i32p, i32p, i32p]
+    R.ref_store_binary.argtypes = [C.c_char_p, C.c_int32, C.c_int32, i32p, i32p]
+    R.ref_load_binary.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    R.ref_pagerank.argtypes = [C.c_int32, C.c_int32, i32p, i32p, C.c_double, C.c_double, C.c_int32, f64p,
+                               C.c_int, C.POINTER(C.c_int32)]
+    R.ref_hop_dist.argtypes = [C.c_int32, C.c_int32, i32p, i32p, C.c_int32, i32p, C.c_int]
+    R.ref_bfs_levels.argtypes = [C.c_int32, C.c_int32, i32p, i32p, C.c_int32, i32p, C.c_int, C.c_int]
+    R.ref_triangle_counting.argtypes = [C.c_int32, C.c_int32, i32p, i32p, C.c_int]
+    R.ref_triangle_counting.restype = C.c_int64
+    R.ref_is_neighbor_many.argtypes = [C.c_int32, C.c_int32, i32p, i32p, C.c_int, i32p, i32p, i32p]
+    return R
+
+
+def sha(*arrs):
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def e32(n):
+    return np.empty(max(n, 1), np.int32)[:n].copy()
+
+
+def ref_graph(R, N, M, seed, a, b, c, permute):
+    begin = np.empty(N + 1, np.int32)
+    raw = e32(M)
+    R.ref_rmat_csr(N, M, seed, a, b, c, int(permute), begin, raw)
+    snode = e32(M)
+    rb = np.empty(N + 1, np.int32)
+    rn = e32(M)
+    R.ref_prepare(N, M, begin, raw, snode, rb, rn)
+    return begin, raw, snode, rb, rn
+
+
+def ref_kernels(R, N, begin, node_idx, root=0, pr_args=(0.001, 0.85, 100), tc=True):
+    M = len(node_idx)
+    rank = np.empty(max(N, 1), np.float64)[:N].copy()
+    it = C.c_int32(0)
+    R.ref_pagerank(N, M, begin, node_idx, pr_args[0], pr_args[1], pr_args[2], rank, 1, C.byref(it))
+    dist = e32(N)
+    R.ref_hop_dist(N, M, begin, node_idx, root, dist, 4)
+    lv = e32(N)
+    R.ref_bfs_levels(N, M, begin, node_idx, root, lv, 4, 1)
+    lv2 = e32(N)
+    R.ref_bfs_levels(N, M, begin, node_idx, root, lv2, 1, 0)
+    assert np.array_equal(lv, lv2), "gm_bfs_template: forward-only vs reverse-assisted differ"
+    assert np.array_equal(dist, lv), "emitted hop_dist vs gm_bfs_template levels differ"
+    T = int(R.ref_triangle_counting(N, M, begin, node_idx, 4)) if tc else None
+    return rank, it.value, dist, T
+
+
+def check_oracle_on(R, name, N, begin, raw_or_sorted, pr_args=(0.001, 0.85, 100), root=0, tc=True):
+    """Run reference + oracle on one CSR; assert agreement; return results."""
+    g = po.Graph(N, begin.copy(), raw_or_sorted.copy()).prepare()
+    rank_r, it_r, dist_r, T_r = ref_kernels(R, N, begin, raw_or_sorted, root, pr_args, tc)
+    rank_o, it_o, _ = po.pagerank(g, *pr_args, nthreads=1)
+    assert it_o == it_r, (name, it_o, it_r)
+    assert np.array_equal(rank_o, rank_r), (name, "pagerank 1-thread not bit-identical",
+                                            np.abs(rank_o - rank_r).max())
+    rank_o8, it_o8, _ = po.pagerank(g, *pr_args, nthreads=8)
+    assert it_o8 == it_r and np.array_equal(rank_o8, rank_r), (name, "pagerank 8-thread")
+    dist_o, _ = po.hop_dist(g, root, nthreads=8)
+    assert np.array_equal(dist_o, dist_r), (name, "hop_dist")
+    assert np.array_equal(po.bfs_queue(g, root), dist_r), (name, "bfs_queue")
+    if tc:
+        assert po.triangle_counting(g) == T_r, (name, "tc")
+        assert po.triangle_counting_merge(g) == T_r, (name, "tc merge", po.triangle_counting_merge(g), T_r)
+    return g, rank_r, it_r, dist_r, T_r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    R = ref_lib()
+    os.makedirs(GOLD, exist_ok=True)
+    manifest = {"generator": "oracle/make_golden.py", "reference": "libshoal/Green-Marl @ /root/reference",
+                "rmat": {}, "hand": {}}
+
+    # ---- 1. drand48 ----
+    ref_s = np.empty(4096, np.float64)
+    R.ref_drand48_stream(1997, 4096, ref_s)
+    assert np.array_equal(po.drand48_stream(1997, 4096), ref_s), "drand48 LCG mismatch"
+    for seed in (0, 1, 12345, -7, 2 ** 31 + 5):
+        t = np.empty(64, np.float64)
+        R.ref_drand48_stream(seed, 64, t)
+        assert np.array_equal(po.drand48_stream(seed, 64), t), seed
+    print("drand48: pinned")
+
+    # ---- 2. RMAT graphs + kernels ----
+    fixtures = {}
+    cases = [(6, False), (6, True), (8, False), (8, True), (10, False), (10, True), (12, False),
+             (14, False), (14, True), (16, False)]
+    for scale, perm in cases:
+        N, M = 1 << scale, 16 << scale
+        name = "rmat%d_%s" % (scale, "perm" if perm else "noperm")
+        begin, raw, snode, rb, rn = ref_graph(R, N, M, 1997, 0.57, 0.19, 0.19, perm)
+        ob, oraw, att = po.rmat_raw_csr(N, M, 1997, 0.57, 0.19, 0.19, perm)
+        assert np.array_equal(ob, begin) and np.array_equal(oraw, raw), (name, "rmat csr")
+        g = po.Graph(N, ob, oraw).prepare()
+        assert np.array_equal(g.node_idx, snode), (name, "semi sort")
+        assert np.array_equal(g.r_begin, rb) and np.array_equal(g.r_node_idx, rn), (name, "reverse")
+        root = 0
+        if perm:  # root 0 may be isolated on permuted graphs: pick the max-out-degree vertex, recorded
+            root = int(np.argmax(np.diff(begin)))
+        tc = scale <= 14
+        _, rank, it, dist, T = check_oracle_on(R, name, N, begin, raw, root=root, tc=tc)
+        # tight-tolerance fixed-iteration run (used by the throughput bench)
+        _, rank20, it20, _, _ = check_oracle_on(R, name + "_20it", N, begin, raw,
+                                                pr_args=(1e-300, 0.85, 20), root=root, tc=False)
+        assert it20 == 20
+        # symmetrised graph for the TC measurement config
+        gs = po.symmetrize(g)
+        Ts = None
+        if scale <= 12:
+            Ts = int(R.ref_triangle_counting(gs.N, gs.M, gs.begin, gs.node_idx, 4))
+            assert po.triangle_counting(gs) == Ts and po.triangle_counting_merge(gs) == Ts, name
+        else:
+            Ts = po.triangle_counting_merge(gs)
+        # is_neighbor probes
+        rng = np.random.default_rng(scale * 2 + perm)
+        qs = rng.integers(0, N, 2000).astype(np.int32)
+        qt = rng.integers(0, N, 2000).astype(np.int32)
+        # half of the probes are real edges
+        eidx = rng.integers(0, M, 1000)
+        src_of = np.repeat(np.arange(N, dtype=np.int32), np.diff(begin))
+        qs[:1000] = src_of[eidx]
+        qt[:1000] = snode[eidx]
+        out_r = e32(2000)
+        R.ref_is_neighbor_many(N, M, begin, raw, 2000, qs, qt, out_r)
+        L = po.lib()
+        out_o = np.array([L.gmo_get_edge_idx_for_src_dest(g.begin, g.node_idx, int(s), int(t))
+                          for s, t in zip(qs, qt)], np.int32)
+        assert np.array_equal(out_o, out_r), (name, "is_neighbor")
+
+        entry = {"N": N, "M": M, "seed": 1997, "abc": [0.57, 0.19, 0.19], "permute": perm, "attempts": att,
+                 "root": root, "pr_iters": it, "tc_directed": T, "tc_symmetrized": Ts, "M_sym": gs.M,
+                 "reached": int((dist != INT_MAX).sum()), "max_level": int(dist[dist != INT_MAX].max()),
+                 "sha_begin": sha(begin), "sha_raw_node_idx": sha(raw), "sha_node_idx": sha(snode),
+                 "sha_r_begin": sha(rb), "sha_r_node_idx": sha(rn), "sha_dist": sha(dist),
+                 "sha_rank_f64": sha(rank), "sha_rank20_f64": sha(rank20),
+                 "rank_sum": float(rank.sum()), "rank_head": [float(x) for x in rank[:4]]}
+        manifest["rmat"][name] = entry
+        if scale <= 10:   # small enough to commit in full
+            fixtures[name] = dict(begin=begin, raw_node_idx=raw, node_idx=snode, r_begin=rb, r_node_idx=rn,
+                                  rank=rank, rank20=rank20, dist=dist)
+        print("%s: pinned (iters=%d, reached=%d, T=%s, Tsym=%s)" % (name, it, entry["reached"], T, Ts))
+
+    # ---- 3. hand graphs ----
+    hand = {}
+    # doc/tutorial.md:241-279 five-node example (expected in-degree sums 5 4 4 0 4 ... total 17)
+    tut_edges = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 4), (2, 3), (2, 4), (3, 4), (4, 0)]
+    hand["empty1"] = (1, [], 0)
+    hand["two_isolated"] = (2, [], 1)
+    hand["self_loop"] = (3, [(0, 0), (0, 1), (1, 1), (1, 2), (2, 0)], 0)
+    hand["multi_edge"] = (4, [(0, 1), (0, 1), (0, 2), (1, 2), (1, 2), (2, 0), (2, 1), (1, 0), (0, 3), (3, 0), (3, 1), (1, 3)], 0)
+    hand["tutorial5"] = (5, tut_edges, 0)
+    hand["path8"] = (8, [(i, i + 1) for i in range(7)], 0)
+    hand["path8_mid"] = (8, [(i, i + 1) for i in range(7)], 3)
+    hand["star64"] = (64, [(0, i) for i in range(1, 64)] + [(i, 0) for i in range(1, 64)], 0)
+    k6 = [(i, j) for i in range(6) for j in range(6) if i != j]
+    hand["k6"] = (6, k6, 2)
+    for name, (N, edges, root) in hand.items():
+        src = np.array([e[0] for e in edges], np.int32)
+        dst = np.array([e[1] for e in edges], np.int32)
+        begin, raw = po.csr_from_edges(N, src, dst)
+        g, rank, it, dist, T = check_oracle_on(R, name, N, begin, raw, root=root, tc=True)
+        fixtures["hand_" + name] = dict(begin=begin, raw_node_idx=raw, node_idx=g.node_idx, r_begin=g.r_begin,
+                                        r_node_idx=g.r_node_idx, rank=rank, dist=dist)
+        manifest["hand"][name] = {"N": N, "M": len(edges), "root": root, "pr_iters": it, "tc": T}
+        print("hand %s: pinned (iters=%d T=%d)" % (name, it, T))
+
+    # ---- 4. binary format ----
+    begin, raw, snode, rb, rn = ref_graph(R, 256, 4096, 1997, 0.57, 0.19, 0.19, False)
+    with tempfile.TemporaryDirectory() as td:
+        p_ref = os.path.join(td, "ref.bin")
+        p_or = os.path.join(td, "or.bin")
+        assert R.ref_store_binary(p_ref.encode(), 256, 4096, begin, snode) == 0
+        go = po.Graph(256, begin, snode)
+        po.store_binary(p_or, go)
+        b_ref = open(p_ref, "rb").read()
+        assert b_ref == open(p_or, "rb").read(), "store_binary bytes differ"
+        gl = po.load_binary(p_ref)
+        assert np.array_equal(gl.begin, begin) and np.array_equal(gl.node_idx, snode)
+        assert np.array_equal(gl.r_begin, rb) and np.array_equal(gl.r_node_idx, rn)
+        # reference load of the oracle-written file
+        N_ = C.c_int32(0)
+        M_ = C.c_int32(0)
+        lb, ln, lrb, lrn = np.empty(257, np.int32), e32(4096), np.empty(257, np.int32), e32(4096)
+        assert R.ref_load_binary(p_or.encode(), C.byref(N_), C.byref(M_), lb.ctypes.data, ln.ctypes.data,
+                                 lrb.ctypes.data, lrn.ctypes.data) == 0
+        assert np.array_equal(lb, begin) and np.array_equal(ln, snode) and np.array_equal(lrn, rn)
+        manifest["bin"] = {"file": "rmat8_ref_store_binary.bin", "N": 256, "M": 4096, "sha256": hashlib.sha256(b_ref).hexdigest()}
+        if not args.check:
+            open(os.path.join(GOLD, "rmat8_ref_store_binary.bin"), "wb").write(b_ref)
+    print("binary format: pinned")
+
+    if not args.check:
+        flat = {}
+        for k, d in fixtures.items():
+            for kk, v in d.items():
+                flat[k + "/" + kk] = v
+        np.savez_compressed(os.path.join(GOLD, "golden.npz"), **flat)
+        json.dump(manifest, open(os.path.join(GOLD, "manifest.json"), "w"), indent=1, sort_keys=True)
+        print("wrote", GOLD)
+    print("ORACLE PINNED OK")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,290 @@
+/*
+ * ref_harness.cc -- TEST INFRASTRUCTURE (never shipped, never on the GPU box).
+ *
+ * A thin extern "C" shim over the REAL reference runtime (libgmgraph objects
+ * compiled from /root/reference/apps/output_cpp/gm_graph/src/*.cc in place by
+ * oracle/Makefile into oracle/_ref/).  oracle/make_golden.py loads the
+ * resulting oracle/_ref/libgmref.so to (1) pin oracle/gm_oracle.c and
+ * (2) generate the committed fixtures under tests/golden/.
+ *
+ * The three emitted kernels are not in the reference tree (generated code is
+ * git-ignored and gm_comp cannot be built here: no flex), so the kernel bodies
+ * below are the plain emission restated against the reference's own gm_graph /
+ * gm_rt_* / ATOMIC_* / spinlock primitives, i.e. they compile and run against
+ * the genuine runtime the generated code would link with.  gm_bfs_template and
+ * gm_graph::is_neighbor are pure reference code and serve as independent
+ * checks of hop_dist and triangle_counting.
+ */
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#include "gm.h"          // reference umbrella header (apps/output_cpp/gm_graph/inc/gm.h)
+#include "graph_gen.h"   // create_RMAT_graph
+
+extern "C" {
+
+/* glibc drand48 stream, to pin gmo_drand48 */
+void ref_drand48_stream(long seed, int n, double* out) {
+    srand48(seed);
+    for (int i = 0; i < n; i++) out[i] = drand48();
+}
+
+/* raw create_RMAT_graph CSR (before any sort) */
+int ref_rmat_csr(int32_t N, int32_t M, long seed, double a, double b, double c, int permute,
+                 int32_t* begin, int32_t* node_idx) {
+    gm_graph* g = create_RMAT_graph(N, M, seed, a, b, c, permute != 0);
+    memcpy(begin, g->begin, sizeof(int32_t) * ((size_t) N + 1));
+    memcpy(node_idx, g->node_idx, sizeof(int32_t) * (size_t) M);
+    delete g;
+    return 0;
+}
+
+static gm_graph* make_graph(int32_t N, int32_t M, const int32_t* begin, const int32_t* node_idx) {
+    gm_graph* g = new gm_graph();
+    g->prepare_external_creation(N, M);
+    memcpy(g->begin, begin, sizeof(int32_t) * ((size_t) N + 1));
+    memcpy(g->node_idx, node_idx, sizeof(int32_t) * (size_t) M);
+    return g;
+}
+
+/* what load_binary does after reading: do_semi_sort + make_reverse_edges
+ * (gm_graph_binary_loader.cc:191-197) */
+int ref_prepare(int32_t N, int32_t M, const int32_t* begin, const int32_t* node_idx,
+                int32_t* s_node_idx, int32_t* r_begin, int32_t* r_node_idx) {
+    gm_graph* g = make_graph(N, M, begin, node_idx);
+    g->do_semi_sort();
+    g->make_reverse_edges();
+    memcpy(s_node_idx, g->node_idx, sizeof(int32_t) * (size_t) M);
+    memcpy(r_begin, g->r_begin, sizeof(int32_t) * ((size_t) N + 1));
+    memcpy(r_node_idx, g->r_node_idx, sizeof(int32_t) * (size_t) M);
+    delete g;
+    return 0;
+}
+
+/* store_binary / load_binary round trip through the reference code */
+int ref_store_binary(const char* path, int32_t N, int32_t M, const int32_t* begin, const int32_t* node_idx) {
+    gm_graph* g = make_graph(N, M, begin, node_idx);
+    bool ok = g->store_binary((char*) path);
+    delete g;
+    return ok ? 0 : -1;
+}
+
+int ref_load_binary(const char* path, int32_t* N, int32_t* M,
+                    int32_t* begin, int32_t* node_idx, int32_t* r_begin, int32_t* r_node_idx) {
+    gm_graph g;
+    if (!g.load_binary((char*) path)) return -1;
+    *N = g.num_nodes();
+    *M = g.num_edges();
+    if (begin) {
+        memcpy(begin, g.begin, sizeof(int32_t) * ((size_t) *N + 1));
+        memcpy(node_idx, g.node_idx, sizeof(int32_t) * (size_t) *M);
+        memcpy(r_begin, g.r_begin, sizeof(int32_t) * ((size_t) *N + 1));
+        memcpy(r_node_idx, g.r_node_idx, sizeof(int32_t) * (size_t) *M);
+    }
+    return 0;
+}
+
+/* ---- pagerank: plain emission against the reference runtime ---- */
+int ref_pagerank(int32_t N_, int32_t M, const int32_t* begin, const int32_t* node_idx,
+                 double e, double d, int32_t max, double* G_pg_rank, int nthreads, int32_t* iters) {
+    gm_graph* gp = make_graph(N_, M, begin, node_idx);
+    gm_graph& G = *gp;
+    G.do_semi_sort();
+    gm_rt_set_num_threads(nthreads);
+
+    //Initializations
+    gm_rt_initialize();
+    G.freeze();
+    G.make_reverse_edges();
+
+    double diff = 0.0;
+    int32_t cnt = 0;
+    double N = 0.0;
+    double* G_pg_rank_nxt = gm_rt_allocate_double(G.num_nodes(), gm_rt_thread_id());
+
+    cnt = 0;
+    N = (double) (G.num_nodes());
+
+    #pragma omp parallel for
+    for (node_t t0 = 0; t0 < G.num_nodes(); t0++)
+        G_pg_rank[t0] = 1 / N;
+
+    do {
+        diff = ((float) (0.000000));
+        #pragma omp parallel
+        {
+            double diff_prv = 0.0;
+            diff_prv = ((float) (0.000000));
+
+            #pragma omp for nowait schedule(dynamic,128)
+            for (node_t t = 0; t < G.num_nodes(); t++) {
+                double val = 0.0;
+                double __S1 = 0.0;
+                __S1 = ((float) (0.000000));
+                for (edge_t w_idx = G.r_begin[t]; w_idx < G.r_begin[t + 1]; w_idx++) {
+                    node_t w = G.r_node_idx[w_idx];
+                    __S1 = __S1 + G_pg_rank[w] / ((double) ((G.begin[w + 1] - G.begin[w])));
+                }
+                val = (1 - d) / N + d * __S1;
+                diff_prv = diff_prv + std::abs((val - G_pg_rank[t]));
+                G_pg_rank_nxt[t] = val;
+            }
+            ATOMIC_ADD<double>(&diff, diff_prv);
+        }
+        #pragma omp parallel for
+        for (node_t i3 = 0; i3 < G.num_nodes(); i3++)
+            G_pg_rank[i3] = G_pg_rank_nxt[i3];
+        cnt = cnt + 1;
+    } while ((diff > e) && (cnt < max));
+
+    gm_rt_cleanup();
+    if (iters) *iters = cnt;
+    delete gp;
+    return 0;
+}
+
+/* ---- hop_dist: plain emission against the reference runtime (spinlock form) ---- */
+int ref_hop_dist(int32_t N, int32_t M, const int32_t* begin, const int32_t* node_idx,
+                 int32_t root_, int32_t* G_dist, int nthreads) {
+    gm_graph* gp = make_graph(N, M, begin, node_idx);
+    gm_graph& G = *gp;
+    node_t root = root_;
+    gm_rt_set_num_threads(nthreads);
+
+    gm_rt_initialize();
+    G.freeze();
+
+    bool fin = false;
+    bool* G_updated = gm_rt_allocate_bool(G.num_nodes(), gm_rt_thread_id());
+    bool* G_updated_nxt = gm_rt_allocate_bool(G.num_nodes(), gm_rt_thread_id());
+    int32_t* G_dist_nxt = gm_rt_allocate_int(G.num_nodes(), gm_rt_thread_id());
+
+    fin = false;
+    #pragma omp parallel for
+    for (node_t t0 = 0; t0 < G.num_nodes(); t0++) {
+        G_dist[t0] = (t0 == root) ? 0 : INT_MAX;
+        G_updated[t0] = (t0 == root) ? true : false;
+        G_dist_nxt[t0] = G_dist[t0];
+        G_updated_nxt[t0] = G_updated[t0];
+    }
+    while (!fin) {
+        bool __E8 = false;
+        fin = true;
+        __E8 = false;
+        #pragma omp parallel for schedule(dynamic,128)
+        for (node_t n = 0; n < G.num_nodes(); n++) {
+            if (G_updated[n]) {
+                for (edge_t s_idx = G.begin[n]; s_idx < G.begin[n + 1]; s_idx++) {
+                    node_t s = G.node_idx[s_idx];
+                    { // argmin(argmax) - test and test-and-set
+                        int32_t dist_nxt_new = G_dist[n] + 1;
+                        if (G_dist_nxt[s] > dist_nxt_new) {
+                            bool updated_nxt_arg = true;
+                            gm_spinlock_acquire_for_node(s);
+                            if (G_dist_nxt[s] > dist_nxt_new) {
+                                G_dist_nxt[s] = dist_nxt_new;
+                                G_updated_nxt[s] = updated_nxt_arg;
+                            }
+                            gm_spinlock_release_for_node(s);
+                        }
+                    }
+                }
+            }
+        }
+        #pragma omp parallel
+        {
+            bool __E8_prv = false;
+            #pragma omp for nowait
+            for (node_t t4 = 0; t4 < G.num_nodes(); t4++) {
+                G_dist[t4] = G_dist_nxt[t4];
+                G_updated[t4] = G_updated_nxt[t4];
+                G_updated_nxt[t4] = false;
+                __E8_prv = __E8_prv || G_updated[t4];
+            }
+            ATOMIC_OR(&__E8, __E8_prv);
+        }
+        fin = !__E8;
+    }
+    gm_rt_cleanup();
+    delete gp;
+    return 0;
+}
+
+/* ---- pure reference BFS: gm_bfs_template (gm_bfs_template.h:14-754) ---- */
+class ref_bfs_t : public gm_bfs_template<short, true, false, false, false>
+{
+  public:
+    ref_bfs_t(gm_graph& g, int32_t* lv) : gm_bfs_template<short, true, false, false, false>(g), level(lv) {}
+  protected:
+    virtual void visit_fw(node_t t) { level[t] = get_curr_level(); }
+    virtual void visit_rv(node_t t) {}
+    virtual bool check_navigator(node_t t, edge_t nx) { return true; }
+  private:
+    int32_t* level;
+};
+
+int ref_bfs_levels(int32_t N, int32_t M, const int32_t* begin, const int32_t* node_idx,
+                   int32_t root, int32_t* level, int nthreads, int with_reverse) {
+    gm_graph* gp = make_graph(N, M, begin, node_idx);
+    gp->do_semi_sort();
+    if (with_reverse) gp->make_reverse_edges();
+    gm_rt_set_num_threads(nthreads);
+    gm_rt_initialize();
+    for (int32_t i = 0; i < N; i++) level[i] = INT_MAX;
+    {
+        ref_bfs_t bfs(*gp, level);
+        bfs.prepare(root, gm_rt_get_num_threads());
+        bfs.do_bfs_forward();
+    }
+    delete gp;
+    return 0;
+}
+
+/* ---- triangle_counting: plain emission, HasEdgeTo through the reference's
+ *      gm_graph::is_neighbor (gm_graph.cc:60-66,589-633) ---- */
+int64_t ref_triangle_counting(int32_t N, int32_t M, const int32_t* begin, const int32_t* node_idx, int nthreads) {
+    gm_graph* gp = make_graph(N, M, begin, node_idx);
+    gm_graph& G = *gp;
+    gm_rt_set_num_threads(nthreads);
+    gm_rt_initialize();
+    G.freeze();
+    G.do_semi_sort();
+
+    int64_t T = 0;
+    #pragma omp parallel
+    {
+        int64_t T_prv = 0;
+        #pragma omp for nowait schedule(dynamic,128)
+        for (node_t v = 0; v < G.num_nodes(); v++) {
+            for (edge_t u_idx = G.begin[v]; u_idx < G.begin[v + 1]; u_idx++) {
+                node_t u = G.node_idx[u_idx];
+                if (u > v) {
+                    for (edge_t w_idx = G.begin[v]; w_idx < G.begin[v + 1]; w_idx++) {
+                        node_t w = G.node_idx[w_idx];
+                        if (w > u) {
+                            if (G.is_neighbor(w, u)) T_prv = T_prv + 1;
+                        }
+                    }
+                }
+            }
+        }
+        ATOMIC_ADD<int64_t>(&T, T_prv);
+    }
+    gm_rt_cleanup();
+    delete gp;
+    return T;
+}
+
+/* is_neighbor probe for direct pinning of gmo_get_edge_idx_for_src_dest */
+int ref_is_neighbor_many(int32_t N, int32_t M, const int32_t* begin, const int32_t* node_idx,
+                         int n, const int32_t* src, const int32_t* to, int32_t* out_edge_idx) {
+    gm_graph* gp = make_graph(N, M, begin, node_idx);
+    gp->do_semi_sort();
+    for (int i = 0; i < n; i++) out_edge_idx[i] = gp->get_edge_idx_for_src_dest(src[i], to[i]);
+    delete gp;
+    return 0;
+}
+
+}  // extern "C"
