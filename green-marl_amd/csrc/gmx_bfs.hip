@@ -1,0 +1,260 @@
+// gmx_bfs.hip -- hop_dist (BFS depth along out-edges) for gfx950.
+//
+// Replaces the body of the emitted `hop_dist` (source /root/reference/apps/src/hop_dist.gm:3-31;
+// restated emission SURVEY.md section 8 a-2): a level-synchronous push where every updated
+// vertex relaxes dist_nxt of its out-neighbours under a per-node lock, INT_MAX = unreached.
+// The result (BFS depth from root) is unique, so the device version is free to choose the
+// traversal: direction-optimising as the reference's own runtime BFS does
+// (apps/output_cpp/gm_graph/inc/gm_bfs_template.h:352-421):
+//   * top-down:  frontier queue; a wave takes 64 frontier vertices, expands rows >= 64 edges
+//                cooperatively (coalesced node_idx reads) and the rest lane-serially;
+//                first-writer-wins via atomicMin on dist (the emitted `min=`), next queue
+//                built with __ballot-aggregated appends;
+//   * bottom-up: when the frontier exceeds 5 % of V (RRD_THRESHOLD, gm_bfs_template.h:359),
+//                every unvisited vertex scans its in-row for a parent whose bit is set in the
+//                frontier bitmap (V/8 bytes: fits L2) and stops at the first hit.
+// Integer only: bit-exact against the CPU result by construction.
+#include "gmx_internal.h"
+
+#include <limits.h>
+#include <string.h>
+
+#define BFS_THREADS 256
+
+struct bfs_counters {
+    unsigned long long next_count;     // vertices discovered in this level
+    unsigned long long edges;          // edges inspected so far
+};
+
+__global__ void bfs_init_kernel(int32_t* __restrict__ dist, int64_t V, int32_t root) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < V; i += stride) dist[i] = (i == root) ? 0 : INT_MAX;
+}
+
+__device__ __forceinline__ void bfs_visit(int32_t s, int32_t next_level, int32_t* __restrict__ dist,
+                                          int32_t* __restrict__ next_q, bfs_counters* __restrict__ ctr) {
+    // <s.dist_nxt; s.updated_nxt> min= <n.dist + 1; True>   (hop_dist.gm:21)
+    bool won = false;
+    if (dist[s] == INT_MAX) won = (atomicMin(&dist[s], next_level) == INT_MAX);
+    unsigned long long m = __ballot(won);
+    if (m) {
+        int lane = threadIdx.x & 63;
+        int leader = __ffsll((long long) m) - 1;
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(&ctr->next_count, (unsigned long long) __popcll(m));
+        base = __shfl(base, leader, 64);
+        if (won) next_q[base + __popcll(m & ((1ULL << lane) - 1))] = s;
+    }
+}
+
+__global__ void __launch_bounds__(BFS_THREADS)
+bfs_topdown_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx,
+                   const int32_t* __restrict__ cur_q, int64_t cur_count, int32_t level,
+                   int32_t* __restrict__ dist, int32_t* __restrict__ next_q, bfs_counters* __restrict__ ctr) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t) gridDim.x * blockDim.x) >> 6;
+    unsigned long long inspected = 0;
+    for (int64_t base = wave * 64; base < cur_count; base += nwaves * 64) {
+        int64_t qi = base + lane;
+        int32_t rb = 0, re = 0;
+        if (qi < cur_count) {
+            int32_t n = cur_q[qi];
+            rb = begin[n];
+            re = begin[n + 1];
+        }
+        // rows with >= 64 edges: the whole wave walks them, coalesced
+        unsigned long long big = __ballot(re - rb >= 64);
+        while (big) {
+            int src_lane = __ffsll((long long) big) - 1;
+            big &= big - 1;
+            int32_t b = __shfl(rb, src_lane, 64), e = __shfl(re, src_lane, 64);
+            for (int32_t i = b + lane; i < e; i += 64) {
+                inspected++;
+                bfs_visit(node_idx[i], level + 1, dist, next_q, ctr);
+            }
+            if (lane == src_lane) re = rb;  // done
+        }
+        // remaining short rows: lane-serial (__ballot only counts the lanes still active)
+        for (int32_t i = rb; i < re; i++) {
+            inspected++;
+            bfs_visit(node_idx[i], level + 1, dist, next_q, ctr);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) inspected += __shfl_down(inspected, off, 64);
+    if (lane == 0 && inspected) atomicAdd(&ctr->edges, inspected);
+}
+
+// bitmap of the vertices in cur_q
+__global__ void bfs_queue_to_bitmap_kernel(const int32_t* __restrict__ q, int64_t n, uint32_t* __restrict__ bm) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        int32_t v = q[i];
+        atomicOr(&bm[v >> 5], 1u << (v & 31));
+    }
+}
+
+// one thread per vertex; unvisited vertices look for a parent in the frontier bitmap
+__global__ void __launch_bounds__(BFS_THREADS)
+bfs_bottomup_kernel(const int32_t* __restrict__ r_begin, const int32_t* __restrict__ r_node_idx, int64_t V,
+                    int32_t level, const uint32_t* __restrict__ frontier_bm, uint32_t* __restrict__ next_bm,
+                    int32_t* __restrict__ dist, bfs_counters* __restrict__ ctr) {
+    int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    unsigned long long inspected = 0, found_cnt = 0;
+    for (; t < V; t += stride) {
+        if (dist[t] != INT_MAX) continue;
+        int32_t b = r_begin[t], e = r_begin[t + 1];
+        for (int32_t i = b; i < e; i++) {
+            int32_t w = r_node_idx[i];
+            inspected++;
+            if (frontier_bm[w >> 5] & (1u << (w & 31))) {
+                dist[t] = level + 1;
+                atomicOr(&next_bm[t >> 5], 1u << (t & 31));
+                found_cnt++;
+                break;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        inspected += __shfl_down(inspected, off, 64);
+        found_cnt += __shfl_down(found_cnt, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (inspected) atomicAdd(&ctr->edges, inspected);
+        if (found_cnt) atomicAdd(&ctr->next_count, found_cnt);
+    }
+}
+
+__global__ void bfs_bitmap_to_queue_kernel(const uint32_t* __restrict__ bm, int64_t V, int32_t* __restrict__ q,
+                                           unsigned long long* __restrict__ qcount) {
+    int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    int64_t vend = (V + stride - 1) / stride * stride;  // keep waves converged
+    for (; v < vend; v += stride) {
+        bool in = v < V && (bm[v >> 5] & (1u << (v & 31)));
+        unsigned long long m = __ballot(in);
+        if (m) {
+            int lane = threadIdx.x & 63;
+            int leader = __ffsll((long long) m) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(qcount, (unsigned long long) __popcll(m));
+            base = __shfl(base, leader, 64);
+            if (in) q[base + __popcll(m & ((1ULL << lane) - 1))] = (int32_t) v;
+        }
+    }
+}
+
+static int grid_for(int64_t n, int block = BFS_THREADS, int max_blocks = 256 * 8) {
+    int64_t b = (n + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int) b;
+}
+
+extern "C" int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host, gmx_stats_t* stats) {
+    GMX_REQUIRE(g && dist_host, "NULL argument");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    const int64_t V = g->V;
+    if (V == 0) return GMX_OK;
+    const bool root_ok = root >= 0 && root < V;   // a root outside the graph reaches nothing
+
+    dbuf<int32_t> dist, q0, q1;
+    dbuf<uint32_t> bm0, bm1;
+    dbuf<bfs_counters> ctr;
+    dbuf<unsigned long long> qcount;
+    const size_t bmw = (size_t) ((V + 31) / 32);
+    GMX_CHECK(dist.alloc((size_t) V));
+    GMX_CHECK(q0.alloc((size_t) V));
+    GMX_CHECK(q1.alloc((size_t) V));
+    GMX_CHECK(ctr.alloc(1));
+    GMX_CHECK(qcount.alloc(1));
+    const bool can_bottom_up = g->has_reverse;
+    if (can_bottom_up) {
+        GMX_CHECK(bm0.alloc(bmw));
+        GMX_CHECK(bm1.alloc(bmw));
+    }
+
+    hipEvent_t ev0, ev1;
+    GMX_HIP(hipEventCreate(&ev0));
+    GMX_HIP(hipEventCreate(&ev1));
+    GMX_HIP(hipEventRecord(ev0, 0));
+
+    hipLaunchKernelGGL(bfs_init_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, dist.p, V, root_ok ? root : -1);
+    int32_t level = 0;
+    int64_t cur_count = 0, reached = 0;
+    unsigned long long edges = 0;
+    if (root_ok) {
+        GMX_HIP(hipMemcpy(q0.p, &root, sizeof(int32_t), hipMemcpyHostToDevice));
+        cur_count = 1;
+        reached = 1;
+    }
+    int32_t* cur_q = q0.p;
+    int32_t* next_q = q1.p;
+    bool frontier_is_bitmap = false;     // true: frontier lives in bm0 (bottom-up produced it)
+    const int64_t bu_threshold = V / 20; // RRD_THRESHOLD = 0.05 (gm_bfs_template.h:359)
+
+    while (cur_count > 0) {
+        bfs_counters zero = {0, edges};
+        GMX_HIP(hipMemcpy(ctr.p, &zero, sizeof(zero), hipMemcpyHostToDevice));
+        const bool bottom_up = can_bottom_up && cur_count > bu_threshold;
+        if (bottom_up) {
+            if (!frontier_is_bitmap) {
+                GMX_HIP(hipMemsetAsync(bm0.p, 0, bmw * 4, 0));
+                hipLaunchKernelGGL(bfs_queue_to_bitmap_kernel, dim3(grid_for(cur_count)), dim3(BFS_THREADS), 0, 0, cur_q, cur_count, bm0.p);
+            }
+            GMX_HIP(hipMemsetAsync(bm1.p, 0, bmw * 4, 0));
+            hipLaunchKernelGGL(bfs_bottomup_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 32)), dim3(BFS_THREADS), 0, 0,
+                               g->r_begin.p, g->r_node_idx.p, V, level, bm0.p, bm1.p, dist.p, ctr.p);
+            uint32_t* t = bm0.p; bm0.p = bm1.p; bm1.p = t;
+            frontier_is_bitmap = true;
+        } else {
+            if (frontier_is_bitmap) {  // came back from bottom-up: rebuild the queue
+                GMX_HIP(hipMemsetAsync(qcount.p, 0, sizeof(unsigned long long), 0));
+                hipLaunchKernelGGL(bfs_bitmap_to_queue_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, bm0.p, V, cur_q, qcount.p);
+                frontier_is_bitmap = false;
+            }
+            int64_t waves = (cur_count + 63) / 64;
+            int blocks = grid_for(waves * 64);
+            hipLaunchKernelGGL(bfs_topdown_kernel, dim3(blocks), dim3(BFS_THREADS), 0, 0,
+                               g->begin.p, g->node_idx.p, cur_q, cur_count, level, dist.p, next_q, ctr.p);
+            int32_t* t = cur_q; cur_q = next_q; next_q = t;
+        }
+        GMX_HIP(hipGetLastError());
+        bfs_counters h;
+        GMX_HIP(hipMemcpy(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost));
+        cur_count = (int64_t) h.next_count;
+        edges = h.edges;
+        reached += cur_count;
+        level++;
+    }
+    GMX_HIP(hipEventRecord(ev1, 0));
+    GMX_HIP(hipEventSynchronize(ev1));
+    float ms = 0;
+    (void) hipEventElapsedTime(&ms, ev0, ev1);
+    hipEvent_t c0, c1;
+    (void) hipEventCreate(&c0);
+    (void) hipEventCreate(&c1);
+    (void) hipEventRecord(c0, 0);
+    GMX_HIP(hipMemcpy(dist_host, dist.p, sizeof(int32_t) * (size_t) V, hipMemcpyDeviceToHost));
+    (void) hipEventRecord(c1, 0);
+    (void) hipEventSynchronize(c1);
+    float cms = 0;
+    (void) hipEventElapsedTime(&cms, c0, c1);
+    (void) hipEventDestroy(c0);
+    (void) hipEventDestroy(c1);
+    (void) hipEventDestroy(ev0);
+    (void) hipEventDestroy(ev1);
+    if (stats) {
+        stats->iterations = level;
+        stats->kernel_ms = ms;
+        stats->d2h_ms = cms;
+        stats->edges_examined = (int64_t) edges;
+        stats->vertices_reached = reached;
+    }
+    return GMX_OK;
+}

@@ -1,0 +1,496 @@
+// gmx_graph.hip -- device graph construction: upload, RMAT generation, CSR build.
+//
+// Replaces (all relative to /root/reference/apps/output_cpp/gm_graph):
+//   src/graph_gen.cc:159-287     create_RMAT_graph          -> rmat_attempts_kernel (+ host permutation)
+//   src/gm_graph.cc:380-503      do_semi_sort               -> 64-bit key radix sort
+//   src/gm_graph.cc:205-304      make_reverse_edges         -> transposed keys + the same sort
+// gfx950 only.  FP contraction is OFF in this file: the RMAT generator must
+// round exactly like the reference's x86-64 build (no FMA).
+#pragma clang fp contract(off)
+
+#include "gmx_internal.h"
+
+#include <math.h>
+#include <string.h>
+#include <rocprim/rocprim.hpp>
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[1024] = "";
+
+void gmx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* gmx_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------ device
+extern "C" int gmx_device_count(int* count) {
+    GMX_REQUIRE(count, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        gmx_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return GMX_ERR_NODEVICE;
+    }
+    *count = n;
+    return GMX_OK;
+}
+
+extern "C" int gmx_set_device(int device) {
+    GMX_HIP(hipSetDevice(device));
+    return GMX_OK;
+}
+
+extern "C" int gmx_device_info(gmx_device_info_t* info) {
+    GMX_REQUIRE(info, "info is NULL");
+    int dev = 0;
+    GMX_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    GMX_HIP(hipGetDeviceProperties(&p, dev));
+    memset(info, 0, sizeof(*info));
+    strncpy(info->name, p.name, sizeof(info->name) - 1);
+    strncpy(info->arch, p.gcnArchName, sizeof(info->arch) - 1);
+    info->compute_units = p.multiProcessorCount;
+    info->clock_mhz = p.clockRate / 1000;
+    info->hbm_bytes = (int64_t) p.totalGlobalMem;
+    info->l2_bytes = p.l2CacheSize;
+    info->lds_bytes_per_cu = (int32_t) p.sharedMemPerMultiprocessor;
+    return GMX_OK;
+}
+
+// ------------------------------------------------------------------ keys <-> CSR
+// key = (row << 32 | col); 2^31 vertices max (node_t is int32).
+__global__ void keys_from_csr_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ idx,
+                                     int64_t V, int64_t E, int transpose, const int32_t* __restrict__ perm,
+                                     uint64_t* __restrict__ keys) {
+    // one thread per edge; the row of an edge is found by binary search on begin[]
+    int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; e < E; e += stride) {
+        int64_t lo = 0, hi = V;  // largest r with begin[r] <= e
+        while (hi - lo > 1) {
+            int64_t mid = (lo + hi) >> 1;
+            if ((int64_t) begin[mid] <= e) lo = mid; else hi = mid;
+        }
+        uint32_t r = (uint32_t) lo, c = (uint32_t) idx[e];
+        if (perm) { r = (uint32_t) perm[r]; c = (uint32_t) perm[c]; }
+        keys[e] = transpose ? (((uint64_t) c << 32) | r) : (((uint64_t) r << 32) | c);
+    }
+}
+
+__global__ void keys_from_edges_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                       int64_t E, int transpose, const int32_t* __restrict__ perm,
+                                       uint64_t* __restrict__ keys) {
+    int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; e < E; e += stride) {
+        uint32_t r = (uint32_t) src[e], c = (uint32_t) dst[e];
+        if (perm) { r = (uint32_t) perm[r]; c = (uint32_t) perm[c]; }
+        keys[e] = transpose ? (((uint64_t) c << 32) | r) : (((uint64_t) r << 32) | c);
+    }
+}
+
+__global__ void csr_extract_kernel(const uint64_t* __restrict__ keys, int64_t V, int64_t E,
+                                   int32_t* __restrict__ begin, int32_t* __restrict__ idx) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (int64_t e = i; e < E; e += stride) idx[e] = (int32_t) (uint32_t) (keys[e] & 0xffffffffu);
+    // begin[r] = first position whose row >= r
+    for (int64_t r = i; r <= V; r += stride) {
+        uint64_t target = (uint64_t) r << 32;
+        int64_t lo = 0, hi = E;  // first index with keys[idx] >= target
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        begin[r] = (int32_t) lo;
+    }
+}
+
+static int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
+    int64_t b = (n + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int) b;
+}
+
+int gmx_keys_from_csr(const int32_t* begin, const int32_t* idx, int64_t V, int64_t E,
+                      bool transpose, const int32_t* perm, uint64_t* keys, hipStream_t stream) {
+    if (E == 0) return GMX_OK;
+    hipLaunchKernelGGL(keys_from_csr_kernel, dim3(grid_for(E)), dim3(256), 0, stream,
+                       begin, idx, V, E, transpose ? 1 : 0, perm, keys);
+    GMX_HIP(hipGetLastError());
+    return GMX_OK;
+}
+
+int gmx_keys_from_edges(const int32_t* src, const int32_t* dst, int64_t E, bool transpose,
+                        const int32_t* perm, uint64_t* keys, hipStream_t stream) {
+    if (E == 0) return GMX_OK;
+    hipLaunchKernelGGL(keys_from_edges_kernel, dim3(grid_for(E)), dim3(256), 0, stream,
+                       src, dst, E, transpose ? 1 : 0, perm, keys);
+    GMX_HIP(hipGetLastError());
+    return GMX_OK;
+}
+
+int gmx_csr_from_keys(uint64_t* keys, uint64_t* keys_alt, int64_t V, int64_t E,
+                      int32_t* begin, int32_t* idx, hipStream_t stream) {
+    const uint64_t* sorted = keys;
+    if (E > 1) {
+        rocprim::double_buffer<uint64_t> db(keys, keys_alt);
+        size_t tmp_bytes = 0;
+        unsigned end_bit = 32 + (unsigned) gmx_bits_for(V);
+        GMX_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, db, (size_t) E, 0u, end_bit, stream));
+        dbuf<char> tmp;
+        GMX_CHECK(tmp.alloc(tmp_bytes));
+        GMX_HIP(rocprim::radix_sort_keys((void*) tmp.p, tmp_bytes, db, (size_t) E, 0u, end_bit, stream));
+        GMX_HIP(hipStreamSynchronize(stream));
+        sorted = db.current();
+    }
+    hipLaunchKernelGGL(csr_extract_kernel, dim3(grid_for(E > V ? E : V + 1)), dim3(256), 0, stream,
+                       sorted, V, E, begin, idx);
+    GMX_HIP(hipGetLastError());
+    GMX_HIP(hipStreamSynchronize(stream));
+    return GMX_OK;
+}
+
+// Build forward (and reverse) CSR of g from device keys (row<<32|col), consuming them.
+static int build_from_forward_keys(gmx_graph* g, dbuf<uint64_t>& keys, dbuf<uint64_t>& alt, bool want_reverse) {
+    hipStream_t s = 0;
+    GMX_CHECK(g->begin.alloc((size_t) g->V + 1));
+    GMX_CHECK(g->node_idx.alloc((size_t) g->E));
+    GMX_CHECK(gmx_csr_from_keys(keys.p, alt.p, g->V, g->E, g->begin.p, g->node_idx.p, s));
+    if (want_reverse) {
+        GMX_CHECK(g->r_begin.alloc((size_t) g->V + 1));
+        GMX_CHECK(g->r_node_idx.alloc((size_t) g->E));
+        GMX_CHECK(gmx_keys_from_csr(g->begin.p, g->node_idx.p, g->V, g->E, true, nullptr, keys.p, s));
+        GMX_CHECK(gmx_csr_from_keys(keys.p, alt.p, g->V, g->E, g->r_begin.p, g->r_node_idx.p, s));
+        g->has_reverse = true;
+    }
+    return GMX_OK;
+}
+
+static int check_sizes(int64_t V, int64_t E) {
+    GMX_REQUIRE(V >= 0 && V < (1LL << 31) - 1, "V=%lld out of int32 node_t range", (long long) V);
+    GMX_REQUIRE(E >= 0 && E < (1LL << 31), "E=%lld out of int32 edge_t range", (long long) E);
+    return GMX_OK;
+}
+
+// ------------------------------------------------------------------ upload
+extern "C" int gmx_graph_upload(const gmx_edge_t* begin, const gmx_node_t* node_idx,
+                                const gmx_edge_t* r_begin, const gmx_node_t* r_node_idx,
+                                int64_t V, int64_t E, uint32_t flags, gmx_graph_t** out) {
+    GMX_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    GMX_CHECK(check_sizes(V, E));
+    GMX_REQUIRE(begin && (node_idx || E == 0), "begin/node_idx is NULL");
+    GMX_REQUIRE(begin[0] == 0 && (int64_t) begin[V] == E, "begin[0]=%d begin[V]=%d do not match E=%lld",
+                begin[0], begin[V], (long long) E);
+    gmx_graph* g = new gmx_graph();
+    g->V = V;
+    g->E = E;
+    (void) hipGetDevice(&g->device);
+    int st = GMX_OK;
+    do {
+        bool want_rev = !(flags & GMX_GRAPH_NO_REVERSE);
+        if ((flags & GMX_GRAPH_SORT_ROWS) || (want_rev && !r_begin)) {
+            // go through keys: sorts rows and/or builds the reverse CSR on the device
+            dbuf<int32_t> tb, ti;
+            dbuf<uint64_t> keys, alt;
+            if ((st = tb.alloc((size_t) V + 1)) || (st = ti.alloc((size_t) E)) ||
+                (st = keys.alloc((size_t) E)) || (st = alt.alloc((size_t) E))) break;
+            if (hipMemcpy(tb.p, begin, sizeof(int32_t) * ((size_t) V + 1), hipMemcpyHostToDevice) != hipSuccess ||
+                (E && hipMemcpy(ti.p, node_idx, sizeof(int32_t) * (size_t) E, hipMemcpyHostToDevice) != hipSuccess)) {
+                gmx_set_error("H2D copy of CSR failed");
+                st = GMX_ERR_HIP;
+                break;
+            }
+            if ((st = gmx_keys_from_csr(tb.p, ti.p, V, E, false, nullptr, keys.p, 0))) break;
+            if ((st = build_from_forward_keys(g, keys, alt, want_rev))) break;
+        } else {
+            if ((st = g->begin.alloc((size_t) V + 1)) || (st = g->node_idx.alloc((size_t) E))) break;
+            if (hipMemcpy(g->begin.p, begin, sizeof(int32_t) * ((size_t) V + 1), hipMemcpyHostToDevice) != hipSuccess ||
+                (E && hipMemcpy(g->node_idx.p, node_idx, sizeof(int32_t) * (size_t) E, hipMemcpyHostToDevice) != hipSuccess)) {
+                gmx_set_error("H2D copy of CSR failed");
+                st = GMX_ERR_HIP;
+                break;
+            }
+            if (want_rev) {
+                if (!(r_node_idx || E == 0)) { gmx_set_error("r_node_idx is NULL"); st = GMX_ERR_ARG; break; }
+                if ((st = g->r_begin.alloc((size_t) V + 1)) || (st = g->r_node_idx.alloc((size_t) E))) break;
+                if (hipMemcpy(g->r_begin.p, r_begin, sizeof(int32_t) * ((size_t) V + 1), hipMemcpyHostToDevice) != hipSuccess ||
+                    (E && hipMemcpy(g->r_node_idx.p, r_node_idx, sizeof(int32_t) * (size_t) E, hipMemcpyHostToDevice) != hipSuccess)) {
+                    gmx_set_error("H2D copy of reverse CSR failed");
+                    st = GMX_ERR_HIP;
+                    break;
+                }
+                g->has_reverse = true;
+            }
+        }
+    } while (0);
+    if (st != GMX_OK) { delete g; return st; }
+    *out = g;
+    return GMX_OK;
+}
+
+extern "C" int gmx_graph_from_edges(const gmx_node_t* src, const gmx_node_t* dst,
+                                    int64_t V, int64_t E, uint32_t flags, gmx_graph_t** out) {
+    GMX_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    GMX_CHECK(check_sizes(V, E));
+    GMX_REQUIRE((src && dst) || E == 0, "src/dst is NULL");
+    for (int64_t i = 0; i < E; i++)
+        GMX_REQUIRE(src[i] >= 0 && src[i] < V && dst[i] >= 0 && dst[i] < V, "edge %lld endpoint out of range", (long long) i);
+    gmx_graph* g = new gmx_graph();
+    g->V = V;
+    g->E = E;
+    (void) hipGetDevice(&g->device);
+    int st = GMX_OK;
+    do {
+        dbuf<int32_t> ds, dd;
+        dbuf<uint64_t> keys, alt;
+        if ((st = ds.alloc((size_t) E)) || (st = dd.alloc((size_t) E)) ||
+            (st = keys.alloc((size_t) E)) || (st = alt.alloc((size_t) E))) break;
+        if (E && (hipMemcpy(ds.p, src, sizeof(int32_t) * (size_t) E, hipMemcpyHostToDevice) != hipSuccess ||
+                  hipMemcpy(dd.p, dst, sizeof(int32_t) * (size_t) E, hipMemcpyHostToDevice) != hipSuccess)) {
+            gmx_set_error("H2D copy of edge list failed");
+            st = GMX_ERR_HIP;
+            break;
+        }
+        if ((st = gmx_keys_from_edges(ds.p, dd.p, E, false, nullptr, keys.p, 0))) break;
+        ds.release();
+        dd.release();
+        if ((st = build_from_forward_keys(g, keys, alt, !(flags & GMX_GRAPH_NO_REVERSE)))) break;
+    } while (0);
+    if (st != GMX_OK) { delete g; return st; }
+    *out = g;
+    return GMX_OK;
+}
+
+// ------------------------------------------------------------------ RMAT on device
+// drand48: X' = (0x5DEECE66D X + 0xB) mod 2^48; value X'/2^48.  A jump by n steps
+// is the affine map x -> a_n x + c_n; jumps by D*2^k steps are tabulated on the
+// host so every thread reaches its first attempt in <= 48 multiply-adds.
+#define LCG_A 0x5DEECE66DULL
+#define LCG_C 0xBULL
+#define LCG_MASK ((1ULL << 48) - 1)
+
+struct lcg_map { uint64_t a, c; };
+struct lcg_table { lcg_map pw[48]; };  // pw[k] = jump by (draws per attempt) * 2^k
+
+static inline lcg_map lcg_then(lcg_map f, lcg_map g) {  // x -> g(f(x))
+    lcg_map r;
+    r.a = (g.a * f.a) & LCG_MASK;
+    r.c = (g.a * f.c + g.c) & LCG_MASK;
+    return r;
+}
+
+static lcg_map lcg_jump(uint64_t n) {  // n single steps
+    lcg_map r = {1, 0}, p = {LCG_A, LCG_C};
+    while (n) {
+        if (n & 1) r = lcg_then(r, p);
+        p = lcg_then(p, p);
+        n >>= 1;
+    }
+    return r;
+}
+
+__device__ __forceinline__ double lcg_next(uint64_t& x) {
+    x = (LCG_A * x + LCG_C) & LCG_MASK;
+    return (double) x * (1.0 / 281474976710656.0);
+}
+
+// One thread = ATT_PER_THREAD consecutive attempts.  Attempt t consumes exactly
+// D = 1 + 5*(SCALE-1) draws (graph_gen.cc:191-227), so its start state is X0
+// advanced t*D steps.  Self loops are rejected by the reference (:231-235):
+// here the slot is appended to bad_slots and refilled by a later round.
+#define ATT_PER_THREAD 8
+__global__ void rmat_attempts_kernel(lcg_table tab, uint64_t x0, int64_t t_begin, int64_t count,
+                                     const int64_t* __restrict__ slot_map,
+                                     int32_t N, int32_t SCALE, double a, double b, double c, double d,
+                                     int32_t* __restrict__ src, int32_t* __restrict__ dst,
+                                     int64_t* __restrict__ bad_slots, unsigned long long* __restrict__ bad_count) {
+    int64_t i0 = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) * ATT_PER_THREAD;
+    if (i0 >= count) return;
+    // jump to attempt t_begin + i0
+    uint64_t t = (uint64_t) (t_begin + i0);
+    uint64_t x = x0;
+    for (int k = 0; k < 48 && (t >> k); k++)
+        if ((t >> k) & 1) x = (tab.pw[k].a * x + tab.pw[k].c) & LCG_MASK;
+
+    int64_t iend = i0 + ATT_PER_THREAD < count ? i0 + ATT_PER_THREAD : count;
+    for (int64_t i = i0; i < iend; i++) {
+        int32_t u = 1, v = 1;
+        int32_t step = N / 2;
+        double av = a, bv = b, cv = c, dv = d;
+        double p = lcg_next(x);
+        if (p < av) {
+        } else if (p < (av + bv)) {
+            v += step;
+        } else if (p < (av + bv + cv)) {
+            u += step;
+        } else {
+            v += step;
+            u += step;
+        }
+        for (int32_t j = 1; j < SCALE; j++) {
+            step = step / 2;
+            double var = 0.1;
+            av *= 0.95 + var * lcg_next(x);
+            bv *= 0.95 + var * lcg_next(x);
+            cv *= 0.95 + var * lcg_next(x);
+            dv *= 0.95 + var * lcg_next(x);
+            double S = av + bv + cv + dv;
+            av = av / S;
+            bv = bv / S;
+            cv = cv / S;
+            dv = dv / S;
+            p = lcg_next(x);
+            if (p < av) {
+            } else if (p < (av + bv)) {
+                v += step;
+            } else if (p < (av + bv + cv)) {
+                u += step;
+            } else {
+                v += step;
+                u += step;
+            }
+        }
+        int64_t slot = slot_map ? slot_map[i] : i;
+        src[slot] = u - 1;
+        dst[slot] = v - 1;
+        if (u == v) {
+            unsigned long long k = atomicAdd(bad_count, 1ULL);
+            bad_slots[k] = slot;
+        }
+    }
+}
+
+__global__ void apply_perm_kernel(int32_t* __restrict__ a, int64_t n, const int32_t* __restrict__ P) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) a[i] = P[a[i]];
+}
+
+extern "C" int gmx_graph_create_rmat(int64_t N, int64_t M, long seed, double a, double b, double c,
+                                     int permute, uint32_t flags, gmx_graph_t** out) {
+    GMX_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    GMX_CHECK(check_sizes(N, M));
+    GMX_REQUIRE(N >= 2, "N must be >= 2");
+    GMX_REQUIRE(a + b + c < 1, "a+b+c must be < 1 (graph_gen.cc:161)");
+    double d = 1 - (a + b + c);
+    int32_t SCALE = (int32_t) log2((double) N);   // graph_gen.cc:179
+    uint64_t D = 1 + 5 * (uint64_t) (SCALE > 1 ? SCALE - 1 : 0);
+    uint64_t x0 = ((((uint64_t) seed) << 16) | 0x330EULL) & LCG_MASK;  // srand48
+
+    lcg_table tab;
+    tab.pw[0] = lcg_jump(D);
+    for (int k = 1; k < 48; k++) tab.pw[k] = lcg_then(tab.pw[k - 1], tab.pw[k - 1]);
+
+    gmx_graph* g = new gmx_graph();
+    g->V = N;
+    g->E = M;
+    (void) hipGetDevice(&g->device);
+    int st = GMX_OK;
+    do {
+        dbuf<int32_t> src, dst;
+        dbuf<int64_t> bad, slots;
+        dbuf<unsigned long long> nbad;
+        size_t bad_cap = (size_t) M + 16;  // worst case: every attempt of a round is a self loop
+        if (bad_cap > (1u << 24)) bad_cap = (size_t) (M / 16) + (1u << 20);
+        if ((st = src.alloc((size_t) M)) || (st = dst.alloc((size_t) M)) || (st = bad.alloc(bad_cap)) ||
+            (st = slots.alloc(bad_cap)) || (st = nbad.alloc(1))) break;
+        int64_t attempts = 0, count = M;
+        bool first = true;
+        hipError_t he = hipSuccess;
+        while (count > 0) {
+            if ((he = hipMemset(nbad.p, 0, sizeof(unsigned long long))) != hipSuccess) break;
+            int64_t threads = (count + ATT_PER_THREAD - 1) / ATT_PER_THREAD;
+            int64_t blocks = (threads + 255) / 256;
+            hipLaunchKernelGGL(rmat_attempts_kernel, dim3((unsigned) blocks), dim3(256), 0, 0,
+                               tab, x0, attempts, count, first ? (const int64_t*) nullptr : (const int64_t*) slots.p,
+                               (int32_t) N, SCALE, a, b, c, d, src.p, dst.p, bad.p, nbad.p);
+            if ((he = hipGetLastError()) != hipSuccess) break;
+            unsigned long long nb = 0;
+            if ((he = hipMemcpy(&nb, nbad.p, sizeof(nb), hipMemcpyDeviceToHost)) != hipSuccess) break;
+            attempts += count;
+            if (nb > bad_cap) { gmx_set_error("rmat: self-loop list overflow (%llu)", nb); st = GMX_ERR_STATE; break; }
+            if (nb) {
+                // the order in which rejected slots are refilled does not matter for the
+                // edge multiset, but keep it deterministic: sort the slot list
+                size_t tb = 0;
+                if ((he = rocprim::radix_sort_keys(nullptr, tb, bad.p, slots.p, (size_t) nb)) != hipSuccess) break;
+                dbuf<char> tmp;
+                if ((st = tmp.alloc(tb))) break;
+                if ((he = rocprim::radix_sort_keys((void*) tmp.p, tb, bad.p, slots.p, (size_t) nb)) != hipSuccess) break;
+                if ((he = hipDeviceSynchronize()) != hipSuccess) break;
+            }
+            count = (int64_t) nb;
+            first = false;
+        }
+        if (st) break;
+        if (he != hipSuccess) { gmx_set_error("rmat generation: %s", hipGetErrorString(he)); st = GMX_ERR_HIP; break; }
+        bad.release();
+        slots.release();
+
+        if (permute) {  // graph_gen.cc:240-259; sequential by construction, N steps on the host
+            std::vector<int32_t> P((size_t) N);
+            for (int64_t i = 0; i < N; i++) P[i] = (int32_t) i;
+            lcg_map j = lcg_jump((uint64_t) attempts * D);
+            uint64_t x = (j.a * x0 + j.c) & LCG_MASK;
+            for (int64_t i = 0; i < N; i++) {
+                x = (LCG_A * x + LCG_C) & LCG_MASK;
+                double r = (double) x * (1.0 / 281474976710656.0);
+                int32_t k = (int32_t) ((int32_t) N * r);
+                int32_t tmp = P[k];
+                P[k] = P[i];
+                P[i] = tmp;
+            }
+            dbuf<int32_t> dP;
+            if ((st = dP.alloc((size_t) N))) break;
+            if (hipMemcpy(dP.p, P.data(), sizeof(int32_t) * (size_t) N, hipMemcpyHostToDevice) != hipSuccess) {
+                gmx_set_error("H2D copy of permutation failed");
+                st = GMX_ERR_HIP;
+                break;
+            }
+            hipLaunchKernelGGL(apply_perm_kernel, dim3(grid_for(M)), dim3(256), 0, 0, src.p, M, dP.p);
+            hipLaunchKernelGGL(apply_perm_kernel, dim3(grid_for(M)), dim3(256), 0, 0, dst.p, M, dP.p);
+            if (hipDeviceSynchronize() != hipSuccess) { gmx_set_error("apply_perm failed"); st = GMX_ERR_HIP; break; }
+        }
+
+        dbuf<uint64_t> keys, alt;
+        if ((st = keys.alloc((size_t) M)) || (st = alt.alloc((size_t) M))) break;
+        if ((st = gmx_keys_from_edges(src.p, dst.p, M, false, nullptr, keys.p, 0))) break;
+        if (hipDeviceSynchronize() != hipSuccess) { gmx_set_error("keys_from_edges failed"); st = GMX_ERR_HIP; break; }
+        src.release();
+        dst.release();
+        if ((st = build_from_forward_keys(g, keys, alt, !(flags & GMX_GRAPH_NO_REVERSE)))) break;
+    } while (0);
+    if (st != GMX_OK) { delete g; return st; }
+    *out = g;
+    return GMX_OK;
+}
+
+// ------------------------------------------------------------------ misc
+extern "C" int gmx_graph_free(gmx_graph_t* g) {
+    delete g;
+    return GMX_OK;
+}
+
+extern "C" int64_t gmx_graph_num_nodes(const gmx_graph_t* g) { return g ? g->V : -1; }
+extern "C" int64_t gmx_graph_num_edges(const gmx_graph_t* g) { return g ? g->E : -1; }
+
+extern "C" int gmx_graph_download(const gmx_graph_t* g, gmx_edge_t* begin, gmx_node_t* node_idx,
+                                  gmx_edge_t* r_begin, gmx_node_t* r_node_idx) {
+    GMX_REQUIRE(g, "graph is NULL");
+    if (begin) GMX_HIP(hipMemcpy(begin, g->begin.p, sizeof(int32_t) * ((size_t) g->V + 1), hipMemcpyDeviceToHost));
+    if (node_idx && g->E) GMX_HIP(hipMemcpy(node_idx, g->node_idx.p, sizeof(int32_t) * (size_t) g->E, hipMemcpyDeviceToHost));
+    if (r_begin || r_node_idx) GMX_REQUIRE(g->has_reverse, "graph has no reverse CSR");
+    if (r_begin) GMX_HIP(hipMemcpy(r_begin, g->r_begin.p, sizeof(int32_t) * ((size_t) g->V + 1), hipMemcpyDeviceToHost));
+    if (r_node_idx && g->E) GMX_HIP(hipMemcpy(r_node_idx, g->r_node_idx.p, sizeof(int32_t) * (size_t) g->E, hipMemcpyDeviceToHost));
+    return GMX_OK;
+}

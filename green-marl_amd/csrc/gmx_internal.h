@@ -1,0 +1,96 @@
+// gmx_internal.h -- shared internals of libgmx (HIP, gfx950 only).
+#ifndef GMX_INTERNAL_H_
+#define GMX_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "gmx.h"
+
+void gmx_set_error(const char* fmt, ...);
+
+#define GMX_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (call);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            gmx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); \
+            return GMX_ERR_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+#define GMX_CHECK(call)                 \
+    do {                                \
+        int _s = (call);                \
+        if (_s != GMX_OK) return _s;    \
+    } while (0)
+
+#define GMX_REQUIRE(cond, ...)          \
+    do {                                \
+        if (!(cond)) {                  \
+            gmx_set_error(__VA_ARGS__); \
+            return GMX_ERR_ARG;         \
+        }                               \
+    } while (0)
+
+// Simple owning device buffer.
+template <typename T>
+struct dbuf {
+    T* p = nullptr;
+    size_t n = 0;
+    dbuf() {}
+    dbuf(const dbuf&) = delete;
+    dbuf& operator=(const dbuf&) = delete;
+    ~dbuf() { release(); }
+    int alloc(size_t count) {
+        release();
+        n = count;
+        size_t bytes = (count ? count : 1) * sizeof(T);
+        hipError_t e = hipMalloc((void**) &p, bytes);
+        if (e != hipSuccess) {
+            p = nullptr;
+            n = 0;
+            gmx_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+            return GMX_ERR_NOMEM;
+        }
+        return GMX_OK;
+    }
+    void release() {
+        if (p) (void) hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    T* take() { T* q = p; p = nullptr; n = 0; return q; }
+};
+
+struct gmx_graph {
+    int64_t V = 0, E = 0;
+    bool has_reverse = false;
+    // original numbering, rows ascending (semi-sorted)
+    dbuf<int32_t> begin, node_idx, r_begin, r_node_idx;
+    int device = 0;
+};
+
+// ---- graph construction helpers (gmx_graph.hip) ----
+// keys are (row << 32 | col).  Sorts keys in place (double buffer), then writes
+// begin[V+1] and idx[E].
+int gmx_csr_from_keys(uint64_t* keys, uint64_t* keys_alt, int64_t V, int64_t E,
+                      int32_t* begin, int32_t* idx, hipStream_t stream);
+// keys[e] = (row(e) << 32 | col(e)) from a CSR; if transpose, (col << 32 | row).
+// perm (optional): map both endpoints through perm[] first.
+int gmx_keys_from_csr(const int32_t* begin, const int32_t* idx, int64_t V, int64_t E,
+                      bool transpose, const int32_t* perm, uint64_t* keys, hipStream_t stream);
+int gmx_keys_from_edges(const int32_t* src, const int32_t* dst, int64_t E, bool transpose,
+                        const int32_t* perm, uint64_t* keys, hipStream_t stream);
+
+static inline int gmx_bits_for(int64_t v) {  // bits needed to represent values in [0, v)
+    int b = 1;
+    while ((1LL << b) < v && b < 32) b++;
+    return b;
+}
+
+#endif

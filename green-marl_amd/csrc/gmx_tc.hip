@@ -1,0 +1,188 @@
+// gmx_tc.hip -- triangle_counting for gfx950.
+//
+// Replaces the body of the emitted `triangle_counting` (source
+// /root/reference/apps/src/triangle_counting.gm:1-13; restated emission SURVEY.md section 8 a-3):
+//     T = #{ (i, j) edge slots of row v : u = node_idx[i] > v, w = node_idx[j] > u, (w -> u) in E }
+// i.e. duplicate slots of row v count multiply, the `w.HasEdgeTo(u)` test is boolean
+// (binary search on the forward row of w, apps/output_cpp/gm_graph/src/shl_graph.cc:14-62).
+// Device formulation: per edge slot (v,u) with u > v, intersect the TAIL of row v (slots with
+// value > u, a sorted multiset) with the IN-row of u (w -> u  <=>  w in r_row(u)).  The shorter
+// side is walked, the longer side is binary searched:
+//   * work <= TC_SMALL: one thread per slot;
+//   * otherwise the slot goes to a list and a whole wave strides over the shorter side
+//     (coalesced reads, per-lane binary search, __shfl_down reduction).
+// Without a reverse CSR the search goes into the forward row of w exactly as emitted.
+// Integer only: exact.
+#include "gmx_internal.h"
+
+#include <string.h>
+
+#define TC_THREADS 256
+#define TC_SMALL 48
+
+__device__ __forceinline__ int32_t tc_lower_bound(const int32_t* __restrict__ a, int32_t lo, int32_t hi, int32_t x) {
+    while (lo < hi) {
+        int32_t mid = lo + ((hi - lo) >> 1);
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ bool tc_contains(const int32_t* __restrict__ a, int32_t lo, int32_t hi, int32_t x) {
+    int32_t p = tc_lower_bound(a, lo, hi, x);
+    return p < hi && a[p] == x;
+}
+
+struct tc_pair { int32_t tb, te, rb, re; };  // tail [tb,te) in node_idx, in-row [rb,re) in r_node_idx (values > u)
+
+// walk `short side`, search `long side`; lanes = 1 (thread) or 64 (wave)
+template <int LANES>
+__device__ __forceinline__ unsigned long long tc_intersect(const int32_t* __restrict__ node_idx,
+                                                           const int32_t* __restrict__ r_node_idx,
+                                                           tc_pair p, int lane) {
+    unsigned long long c = 0;
+    const int32_t tl = p.te - p.tb, rl = p.re - p.rb;
+    if (tl <= rl) {
+        // every tail slot (with multiplicity) that occurs in the in-row
+        for (int32_t j = p.tb + lane; j < p.te; j += LANES)
+            c += tc_contains(r_node_idx, p.rb, p.re, node_idx[j]) ? 1 : 0;
+    } else {
+        // every DISTINCT value of the in-row, times its multiplicity in the tail
+        for (int32_t k = p.rb + lane; k < p.re; k += LANES) {
+            int32_t x = r_node_idx[k];
+            if (k > p.rb && r_node_idx[k - 1] == x) continue;
+            int32_t lo = tc_lower_bound(node_idx, p.tb, p.te, x);
+            int32_t hi = tc_lower_bound(node_idx, lo, p.te, x + 1);
+            c += (unsigned long long) (hi - lo);
+        }
+    }
+    return c;
+}
+
+__global__ void __launch_bounds__(TC_THREADS)
+tc_slots_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx,
+                const int32_t* __restrict__ r_begin, const int32_t* __restrict__ r_node_idx,
+                int64_t V, int64_t E, tc_pair* __restrict__ big, unsigned long long* __restrict__ nbig,
+                unsigned long long* __restrict__ total) {
+    int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    unsigned long long c = 0;
+    for (; e < E; e += stride) {
+        // v = row of slot e
+        int64_t lo = 0, hi = V;
+        while (hi - lo > 1) {
+            int64_t mid = (lo + hi) >> 1;
+            if ((int64_t) begin[mid] <= e) lo = mid; else hi = mid;
+        }
+        const int32_t v = (int32_t) lo, u = node_idx[e];
+        if (u <= v) continue;
+        tc_pair p;
+        p.te = begin[v + 1];
+        p.tb = tc_lower_bound(node_idx, (int32_t) e, p.te, u + 1);
+        if (p.tb >= p.te) continue;
+        p.re = r_begin[u + 1];
+        p.rb = tc_lower_bound(r_node_idx, r_begin[u], p.re, u + 1);
+        if (p.rb >= p.re) continue;
+        const int32_t tl = p.te - p.tb, rl = p.re - p.rb;
+        if ((tl < rl ? tl : rl) <= TC_SMALL) c += tc_intersect<1>(node_idx, r_node_idx, p, 0);
+        else big[atomicAdd(nbig, 1ULL)] = p;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, c);
+}
+
+__global__ void __launch_bounds__(TC_THREADS)
+tc_big_kernel(const int32_t* __restrict__ node_idx, const int32_t* __restrict__ r_node_idx,
+              const tc_pair* __restrict__ big, unsigned long long nbig, unsigned long long* __restrict__ total) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long wave = ((unsigned long long) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned long long nwaves = ((unsigned long long) gridDim.x * blockDim.x) >> 6;
+    unsigned long long c = 0;
+    for (; wave < nbig; wave += nwaves) c += tc_intersect<64>(node_idx, r_node_idx, big[wave], lane);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if (lane == 0 && c) atomicAdd(total, c);
+}
+
+// emitted form (no reverse CSR): thread per slot pair is hopeless on hubs, so one wave per
+// slot (v,u) strides over the tail and binary searches u in the forward row of w.
+__global__ void __launch_bounds__(TC_THREADS)
+tc_forward_only_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx,
+                       int64_t V, int64_t E, unsigned long long* __restrict__ total) {
+    const int lane = threadIdx.x & 63;
+    int64_t e = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t) gridDim.x * blockDim.x) >> 6;
+    unsigned long long c = 0;
+    for (; e < E; e += nwaves) {
+        int64_t lo = 0, hi = V;
+        while (hi - lo > 1) {
+            int64_t mid = (lo + hi) >> 1;
+            if ((int64_t) begin[mid] <= e) lo = mid; else hi = mid;
+        }
+        const int32_t v = (int32_t) lo, u = node_idx[e];
+        if (u <= v) continue;
+        const int32_t te = begin[v + 1];
+        const int32_t tb = tc_lower_bound(node_idx, (int32_t) e, te, u + 1);
+        for (int32_t j = tb + lane; j < te; j += 64) {
+            const int32_t w = node_idx[j];
+            c += tc_contains(node_idx, begin[w], begin[w + 1], u) ? 1 : 0;   // w.HasEdgeTo(u)
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if (lane == 0 && c) atomicAdd(total, c);
+}
+
+extern "C" int gmx_triangle_counting(gmx_graph_t* g, int64_t* count, gmx_stats_t* stats) {
+    GMX_REQUIRE(g && count, "NULL argument");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    *count = 0;
+    if (g->E == 0) return GMX_OK;
+    dbuf<unsigned long long> ctr;   // [0] total, [1] nbig
+    GMX_CHECK(ctr.alloc(2));
+    GMX_HIP(hipMemset(ctr.p, 0, 2 * sizeof(unsigned long long)));
+    hipEvent_t ev0, ev1;
+    GMX_HIP(hipEventCreate(&ev0));
+    GMX_HIP(hipEventCreate(&ev1));
+    GMX_HIP(hipEventRecord(ev0, 0));
+    int64_t blocks = (g->E + TC_THREADS - 1) / TC_THREADS;
+    if (g->has_reverse) {
+        dbuf<tc_pair> big;
+        GMX_CHECK(big.alloc((size_t) g->E));
+        if (blocks > 256 * 64) blocks = 256 * 64;
+        hipLaunchKernelGGL(tc_slots_kernel, dim3((unsigned) blocks), dim3(TC_THREADS), 0, 0,
+                           g->begin.p, g->node_idx.p, g->r_begin.p, g->r_node_idx.p, g->V, g->E, big.p, ctr.p + 1, ctr.p);
+        GMX_HIP(hipGetLastError());
+        unsigned long long h[2];
+        GMX_HIP(hipMemcpy(h, ctr.p, sizeof(h), hipMemcpyDeviceToHost));
+        if (h[1]) {
+            int64_t wb = (int64_t) ((h[1] * 64 + TC_THREADS - 1) / TC_THREADS);
+            if (wb > 256 * 64) wb = 256 * 64;
+            hipLaunchKernelGGL(tc_big_kernel, dim3((unsigned) wb), dim3(TC_THREADS), 0, 0,
+                               g->node_idx.p, g->r_node_idx.p, big.p, h[1], ctr.p);
+            GMX_HIP(hipGetLastError());
+        }
+        GMX_HIP(hipDeviceSynchronize());
+    } else {
+        int64_t wb = (g->E * 64 + TC_THREADS - 1) / TC_THREADS;
+        if (wb > 256 * 64) wb = 256 * 64;
+        hipLaunchKernelGGL(tc_forward_only_kernel, dim3((unsigned) wb), dim3(TC_THREADS), 0, 0,
+                           g->begin.p, g->node_idx.p, g->V, g->E, ctr.p);
+        GMX_HIP(hipGetLastError());
+    }
+    GMX_HIP(hipEventRecord(ev1, 0));
+    GMX_HIP(hipEventSynchronize(ev1));
+    float ms = 0;
+    (void) hipEventElapsedTime(&ms, ev0, ev1);
+    (void) hipEventDestroy(ev0);
+    (void) hipEventDestroy(ev1);
+    unsigned long long h = 0;
+    GMX_HIP(hipMemcpy(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost));
+    *count = (int64_t) h;
+    if (stats) {
+        stats->iterations = 1;
+        stats->kernel_ms = ms;
+    }
+    return GMX_OK;
+}

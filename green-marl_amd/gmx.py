@@ -1,0 +1,294 @@
+"""ctypes binding of libgmx.so -- the Python host-side mirror of the C ABI in include/gmx.h.
+
+The product path.  There is NO CPU fallback here: if libgmx.so is missing or no
+gfx950 device is visible, every compute entry raises.  (The CPU oracle lives in
+oracle/ and is only ever loaded by tests / smoke / bench's cpu_baseline leg.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgmx.so")
+
+GMX_GRAPH_SORT_ROWS = 0x1
+GMX_GRAPH_NO_REVERSE = 0x2
+GMX_PR_RELABEL = 0x1
+GMX_PR_HOT_LDS = 0x2
+INT_MAX = 2147483647
+
+
+class GmxError(RuntimeError):
+    pass
+
+
+class Stats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("reserved", C.c_int32), ("last_diff", C.c_double),
+                ("kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
+                ("edges_examined", C.c_int64), ("vertices_reached", C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 32), ("compute_units", C.c_int32),
+                ("clock_mhz", C.c_int32), ("hbm_bytes", C.c_int64), ("l2_bytes", C.c_int32),
+                ("lds_bytes_per_cu", C.c_int32)]
+
+
+EXPORTS = [
+    "gmx_last_error", "gmx_device_count", "gmx_set_device", "gmx_device_info",
+    "gmx_graph_upload", "gmx_graph_from_edges", "gmx_graph_create_rmat", "gmx_graph_free",
+    "gmx_graph_num_nodes", "gmx_graph_num_edges", "gmx_graph_download",
+    "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_triangle_counting",
+    "gmx_pr_create", "gmx_pr_free", "gmx_pr_reset", "gmx_pr_step", "gmx_pr_contrib_slice",
+    "gmx_pr_contrib_full", "gmx_pr_diff_ptr", "gmx_pr_diff", "gmx_pr_download", "gmx_pr_work",
+]
+
+_LIB = None
+
+
+def lib():
+    """Load libgmx.so (raises if the HIP extension has not been built)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise GmxError("libgmx.so not built: run `make -C green-marl_amd lib` (or __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
+        L.gmx_last_error.restype = C.c_char_p
+        L.gmx_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.gmx_set_device.argtypes = [C.c_int]
+        L.gmx_device_info.argtypes = [C.POINTER(DeviceInfo)]
+        L.gmx_graph_upload.argtypes = [vp, vp, vp, vp, i64, i64, C.c_uint32, C.POINTER(vp)]
+        L.gmx_graph_from_edges.argtypes = [vp, vp, i64, i64, C.c_uint32, C.POINTER(vp)]
+        L.gmx_graph_create_rmat.argtypes = [i64, i64, C.c_long, C.c_double, C.c_double, C.c_double, C.c_int,
+                                            C.c_uint32, C.POINTER(vp)]
+        L.gmx_graph_free.argtypes = [vp]
+        L.gmx_graph_num_nodes.argtypes = [vp]
+        L.gmx_graph_num_nodes.restype = i64
+        L.gmx_graph_num_edges.argtypes = [vp]
+        L.gmx_graph_num_edges.restype = i64
+        L.gmx_graph_download.argtypes = [vp, vp, vp, vp, vp]
+        L.gmx_pagerank_f64.argtypes = [vp, C.c_double, C.c_double, i32, vp, C.POINTER(Stats)]
+        L.gmx_pagerank_f32.argtypes = [vp, C.c_float, C.c_float, i32, vp, C.POINTER(Stats)]
+        L.gmx_hop_dist.argtypes = [vp, i32, vp, C.POINTER(Stats)]
+        L.gmx_triangle_counting.argtypes = [vp, C.POINTER(i64), C.POINTER(Stats)]
+        L.gmx_pr_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(vp)]
+        L.gmx_pr_free.argtypes = [vp]
+        L.gmx_pr_reset.argtypes = [vp, C.c_double]
+        L.gmx_pr_step.argtypes = [vp, vp]
+        L.gmx_pr_contrib_slice.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+        L.gmx_pr_contrib_full.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+        L.gmx_pr_diff_ptr.argtypes = [vp, C.POINTER(vp)]
+        L.gmx_pr_diff.argtypes = [vp, vp, C.POINTER(C.c_double)]
+        L.gmx_pr_download.argtypes = [vp, vp]
+        L.gmx_pr_work.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+        _LIB = L
+    return _LIB
+
+
+def _ck(status):
+    if status != 0:
+        raise GmxError("gmx status %d: %s" % (status, lib().gmx_last_error().decode(errors="replace")))
+
+
+def device_count():
+    n = C.c_int(0)
+    st = lib().gmx_device_count(C.byref(n))
+    return n.value if st == 0 else 0
+
+
+def require_device():
+    if device_count() < 1:
+        raise GmxError("no HIP device visible: the gmx hot path has no CPU fallback")
+
+
+def set_device(i):
+    _ck(lib().gmx_set_device(i))
+
+
+def device_info():
+    d = DeviceInfo()
+    _ck(lib().gmx_device_info(C.byref(d)))
+    return {"name": d.name.decode(), "arch": d.arch.decode(), "compute_units": d.compute_units,
+            "clock_mhz": d.clock_mhz, "hbm_bytes": d.hbm_bytes, "l2_bytes": d.l2_bytes,
+            "lds_bytes_per_cu": d.lds_bytes_per_cu}
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+class Graph:
+    """Device-resident CSR (+ reverse CSR) in gm_graph's layout."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    # -- constructors ------------------------------------------------------
+    @classmethod
+    def upload(cls, begin, node_idx, r_begin=None, r_node_idx=None, flags=0):
+        require_device()
+        begin, node_idx = _i32(begin), _i32(node_idx)
+        V, E = len(begin) - 1, len(node_idx)
+        h = C.c_void_p()
+        rb = _i32(r_begin) if r_begin is not None else None
+        rn = _i32(r_node_idx) if r_node_idx is not None else None
+        _ck(lib().gmx_graph_upload(begin.ctypes.data, node_idx.ctypes.data if E else None,
+                                   rb.ctypes.data if rb is not None else None,
+                                   rn.ctypes.data if (rn is not None and E) else None,
+                                   V, E, flags, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_edges(cls, V, src, dst, flags=0):
+        require_device()
+        src, dst = _i32(src), _i32(dst)
+        h = C.c_void_p()
+        E = len(src)
+        _ck(lib().gmx_graph_from_edges(src.ctypes.data if E else None, dst.ctypes.data if E else None,
+                                       V, E, flags, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def rmat(cls, N, M, seed=1997, a=0.57, b=0.19, c=0.19, permute=False, flags=0):
+        require_device()
+        h = C.c_void_p()
+        _ck(lib().gmx_graph_create_rmat(N, M, seed, a, b, c, int(permute), flags, C.byref(h)))
+        return cls(h)
+
+    # -- accessors ---------------------------------------------------------
+    @property
+    def V(self):
+        return lib().gmx_graph_num_nodes(self._h)
+
+    @property
+    def E(self):
+        return lib().gmx_graph_num_edges(self._h)
+
+    def download(self, reverse=True):
+        V, E = self.V, self.E
+        begin = np.empty(V + 1, np.int32)
+        node_idx = np.empty(max(E, 1), np.int32)[:E].copy()
+        rb = rn = None
+        if reverse:
+            rb = np.empty(V + 1, np.int32)
+            rn = np.empty(max(E, 1), np.int32)[:E].copy()
+        _ck(lib().gmx_graph_download(self._h, begin.ctypes.data, node_idx.ctypes.data,
+                                     rb.ctypes.data if reverse else None, rn.ctypes.data if reverse else None))
+        return begin, node_idx, rb, rn
+
+    def free(self):
+        if self._h:
+            lib().gmx_graph_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    # -- the three kernels (mirror of the generated entry points) ----------
+    def pagerank(self, e=0.001, d=0.85, max_iter=100, dtype=np.float64):
+        """pagerank(G, e, d, max, G_pg_rank) -- returns (rank, stats)."""
+        rank = np.empty(max(self.V, 1), dtype)[: self.V].copy()
+        st = Stats()
+        if dtype == np.float64:
+            _ck(lib().gmx_pagerank_f64(self._h, e, d, max_iter, rank.ctypes.data, C.byref(st)))
+        elif dtype == np.float32:
+            _ck(lib().gmx_pagerank_f32(self._h, e, d, max_iter, rank.ctypes.data, C.byref(st)))
+        else:
+            raise GmxError("dtype must be float32 or float64")
+        return rank, st.as_dict()
+
+    def hop_dist(self, root=0):
+        """hop_dist(G, G_dist, root) -- returns (dist, stats)."""
+        dist = np.empty(max(self.V, 1), np.int32)[: self.V].copy()
+        st = Stats()
+        _ck(lib().gmx_hop_dist(self._h, root, dist.ctypes.data, C.byref(st)))
+        return dist, st.as_dict()
+
+    def triangle_counting(self):
+        """triangle_counting(G) -- returns (T, stats)."""
+        t = C.c_int64(0)
+        st = Stats()
+        _ck(lib().gmx_triangle_counting(self._h, C.byref(t), C.byref(st)))
+        return t.value, st.as_dict()
+
+
+class DevArray:
+    """A raw device pointer exposed through __cuda_array_interface__ so that torch can wrap it
+    (torch.as_tensor(DevArray(...), device='cuda')) for torch.distributed collectives."""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class PageRankState:
+    """Device-resident PageRank stepping state (gmx_pr_*) for one rank of nranks."""
+
+    def __init__(self, graph, elem_bytes=4, rank=0, nranks=1, options=GMX_PR_RELABEL):
+        self.graph = graph
+        self.elem = elem_bytes
+        self.rank, self.nranks = rank, nranks
+        h = C.c_void_p()
+        _ck(lib().gmx_pr_create(graph._h, elem_bytes, rank, nranks, options, C.byref(h)))
+        self._h = h
+
+    def reset(self, d=0.85):
+        _ck(lib().gmx_pr_reset(self._h, d))
+
+    def step(self, stream=None):
+        _ck(lib().gmx_pr_step(self._h, stream))
+
+    def diff(self, stream=None):
+        v = C.c_double(0)
+        _ck(lib().gmx_pr_diff(self._h, stream, C.byref(v)))
+        return v.value
+
+    def _typestr(self):
+        return "<f4" if self.elem == 4 else "<f8"
+
+    def contrib_slice(self):
+        p, n = C.c_void_p(), C.c_int64(0)
+        _ck(lib().gmx_pr_contrib_slice(self._h, C.byref(p), C.byref(n)))
+        return DevArray(p.value, n.value, self._typestr())
+
+    def contrib_full(self):
+        p, n = C.c_void_p(), C.c_int64(0)
+        _ck(lib().gmx_pr_contrib_full(self._h, C.byref(p), C.byref(n)))
+        return DevArray(p.value, n.value, self._typestr())
+
+    def diff_dev(self):
+        p = C.c_void_p()
+        _ck(lib().gmx_pr_diff_ptr(self._h, C.byref(p)))
+        return DevArray(p.value, 1, "<f8")
+
+    def download(self, out=None):
+        V = self.graph.V
+        dt = np.float32 if self.elem == 4 else np.float64
+        if out is None:
+            out = np.zeros(max(V, 1), dt)[:V].copy()
+        _ck(lib().gmx_pr_download(self._h, out.ctypes.data))
+        return out
+
+    def work(self):
+        e, r, b = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _ck(lib().gmx_pr_work(self._h, C.byref(e), C.byref(r), C.byref(b)))
+        return {"edges": e.value, "rows": r.value, "algorithmic_bytes": b.value}
+
+    def free(self):
+        if self._h:
+            lib().gmx_pr_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

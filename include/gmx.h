@@ -1,0 +1,158 @@
+/*
+ * gmx.h -- C ABI of the MI355X-native Green-Marl graph-kernel hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI: its hot path is the
+ * body of three generated C++ functions
+ *     void    pagerank(gm_graph& G, double e, double d, int32_t max, double* G_pg_rank);
+ *     void    hop_dist(gm_graph& G, int32_t* G_dist, node_t& root);
+ *     int64_t triangle_counting(gm_graph& G);
+ * (signature rules: /root/reference/src/backend_cpp/gm_cpp_gen.cc:520-608,938-1017;
+ *  call sites: apps/output_cpp/src/pagerank_main.cc:28, hop_dist_main.cc:28,
+ *  triangle_counting_main.cc:14) that read gm_graph's public CSR arrays
+ * (apps/output_cpp/gm_graph/inc/gm_graph.h:133-142).  The C++ entries with
+ * exactly those signatures live in green-marl_amd/generated/ and are a few
+ * lines each: they hand gm_graph's raw arrays to the functions below.
+ * Everything here is extern "C", plain pointers and sizes, int status returns
+ * (0 = ok; the reference has no error channel, so the C++ entries turn a
+ * non-zero status into fprintf(stderr)+abort()).
+ *
+ * All file:line citations are relative to /root/reference.
+ */
+#ifndef GMX_H_
+#define GMX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMX_OK            0
+#define GMX_ERR_ARG      -1   /* bad argument                       */
+#define GMX_ERR_HIP      -2   /* a HIP runtime call failed          */
+#define GMX_ERR_NODEVICE -3   /* no gfx950 device visible           */
+#define GMX_ERR_NOMEM    -4
+#define GMX_ERR_STATE    -5   /* object not in the required state   */
+
+/* node_t / edge_t are int32 (gm_graph_typedef.h:17-18, the reference default). */
+typedef int32_t gmx_node_t;
+typedef int32_t gmx_edge_t;
+
+typedef struct gmx_graph gmx_graph_t;     /* device-resident CSR (+ reverse CSR) */
+typedef struct gmx_pr    gmx_pr_t;        /* device-resident PageRank state      */
+
+/* Message for the last non-zero status returned on this thread. */
+const char* gmx_last_error(void);
+
+/* ---- device ---- */
+int gmx_device_count(int* count);
+int gmx_set_device(int device);
+typedef struct {
+    char     name[128];
+    char     arch[32];          /* "gfx950..." */
+    int32_t  compute_units;
+    int32_t  clock_mhz;
+    int64_t  hbm_bytes;
+    int32_t  l2_bytes;
+    int32_t  lds_bytes_per_cu;
+} gmx_device_info_t;
+int gmx_device_info(gmx_device_info_t* info);
+
+/* ---- graph: replaces the emitted prologue `G.freeze(); G.make_reverse_edges();
+ *      [G.do_semi_sort();]` + Shoal copy-in (gm_cpp_gen.cc:1307-1368, 670-778) ---- */
+
+#define GMX_GRAPH_SORT_ROWS    0x1u  /* rows of node_idx are not sorted yet: do_semi_sort on device   */
+#define GMX_GRAPH_NO_REVERSE   0x2u  /* do not keep a reverse CSR (BFS top-down only / TC binary search) */
+
+/* Upload a host CSR.  begin[V+1], node_idx[E] = gm_graph::begin / node_idx.
+ * r_begin / r_node_idx = gm_graph::r_begin / r_node_idx, or NULL: the reverse
+ * CSR is then built on the device (gm_graph::make_reverse_edges, gm_graph.cc:205-304,
+ * followed by do_semi_sort_reverse, :461-466). */
+int gmx_graph_upload(const gmx_edge_t* begin, const gmx_node_t* node_idx,
+                     const gmx_edge_t* r_begin, const gmx_node_t* r_node_idx,
+                     int64_t V, int64_t E, uint32_t flags, gmx_graph_t** out);
+
+/* Build from an unordered host edge list (src[i] -> dst[i]); rows come out
+ * semi-sorted, multi-edges and self loops are kept. */
+int gmx_graph_from_edges(const gmx_node_t* src, const gmx_node_t* dst,
+                         int64_t V, int64_t E, uint32_t flags, gmx_graph_t** out);
+
+/* create_RMAT_graph(N, M, rseed, a, b, c, permute) on the device, bit-compatible
+ * with the reference's srand48/drand48 stream (graph_gen.cc:159-287), followed by
+ * do_semi_sort + make_reverse_edges as load_binary does
+ * (gm_graph_binary_loader.cc:191-197). */
+int gmx_graph_create_rmat(int64_t N, int64_t M, long seed, double a, double b, double c,
+                          int permute, uint32_t flags, gmx_graph_t** out);
+
+int gmx_graph_free(gmx_graph_t* g);
+int64_t gmx_graph_num_nodes(const gmx_graph_t* g);
+int64_t gmx_graph_num_edges(const gmx_graph_t* g);
+/* Copy the device CSR back (any pointer may be NULL).  Lets a host gm_graph be
+ * filled from a device-generated graph. */
+int gmx_graph_download(const gmx_graph_t* g, gmx_edge_t* begin, gmx_node_t* node_idx,
+                       gmx_edge_t* r_begin, gmx_node_t* r_node_idx);
+
+/* ---- run statistics (all optional outputs) ---- */
+typedef struct {
+    int32_t iterations;       /* pagerank: cnt; hop_dist: levels; tc: 1          */
+    int32_t reserved;
+    double  last_diff;        /* pagerank: diff of the last iteration            */
+    double  kernel_ms;        /* device time of the timed hot loop (hipEvents)   */
+    double  h2d_ms;           /* property copy-in  (Shoal copy-in analogue)      */
+    double  d2h_ms;           /* property copy-out (Shoal copy-back analogue)    */
+    int64_t edges_examined;   /* hop_dist: edges actually inspected              */
+    int64_t vertices_reached; /* hop_dist                                         */
+} gmx_stats_t;
+
+/* ---- whole-kernel entries (what the three generated C++ functions call) ---- */
+
+/* pagerank(G, e, d, max, G_pg_rank): fp64 storage + fp64 arithmetic.
+ * rank_host[V] is caller-owned (pagerank_main.cc:18-25) and written on return. */
+int gmx_pagerank_f64(gmx_graph_t* g, double e, double d, int32_t max_iter,
+                     double* rank_host, gmx_stats_t* stats);
+/* Node_Prop<Float> variant (BASELINE config 2): fp32 storage, fp64 row sums. */
+int gmx_pagerank_f32(gmx_graph_t* g, float e, float d, int32_t max_iter,
+                     float* rank_host, gmx_stats_t* stats);
+
+/* hop_dist(G, G_dist, root): BFS depth along out-edges, INT_MAX = unreached. */
+int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host, gmx_stats_t* stats);
+
+/* triangle_counting(G) with the emitted multiplicity rule. */
+int gmx_triangle_counting(gmx_graph_t* g, int64_t* count, gmx_stats_t* stats);
+
+/* ---- device-resident PageRank stepping (bench.py / multi-GPU driver) ----
+ * A gmx_pr_t owns the rows [row_lo,row_hi) of the (internally relabelled) graph
+ * and a full replica of the contribution vector.  One step = one PageRank
+ * iteration over the owned rows.  With nranks > 1 the caller exchanges the
+ * owned slice of the new contribution vector between steps (all-gather over
+ * RCCL); slices are equal sized and contiguous by construction. */
+#define GMX_PR_F32 4
+#define GMX_PR_F64 8
+/* options bit flags */
+#define GMX_PR_RELABEL   0x1u   /* degree-sorted internal numbering (default on in whole-kernel entries) */
+#define GMX_PR_HOT_LDS   0x2u   /* keep the hottest contributions in LDS */
+int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nranks, uint32_t options, gmx_pr_t** out);
+int gmx_pr_free(gmx_pr_t* p);
+int gmx_pr_reset(gmx_pr_t* p, double d);                 /* rank = 1/N, contrib = rank/outdeg, cnt = 0 */
+/* Enqueue one iteration on `stream` (a hipStream_t, NULL = default stream). Asynchronous. */
+int gmx_pr_step(gmx_pr_t* p, void* stream);
+/* Device pointer + element count of the slice of the *current* contribution
+ * vector this rank produced in the last step (for the exchange), and of the
+ * whole replica. */
+int gmx_pr_contrib_slice(gmx_pr_t* p, void** dev_ptr, int64_t* count);
+int gmx_pr_contrib_full(gmx_pr_t* p, void** dev_ptr, int64_t* count);
+/* Device pointer to the fp64 `diff` partial of the last step (1 element). */
+int gmx_pr_diff_ptr(gmx_pr_t* p, void** dev_ptr);
+/* Blocking: returns diff of the last step (local rows only). */
+int gmx_pr_diff(gmx_pr_t* p, void* stream, double* diff);
+/* Blocking: ranks of the owned rows scattered into rank_host[V] at original
+ * vertex ids (other entries untouched). */
+int gmx_pr_download(gmx_pr_t* p, void* rank_host);
+/* Algorithmic bytes / edges one step of this rank processes. */
+int gmx_pr_work(gmx_pr_t* p, int64_t* edges, int64_t* rows, int64_t* algorithmic_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

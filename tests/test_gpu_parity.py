@@ -1,0 +1,195 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (libgmx.so via ctypes),
+against the CPU oracle on the same inputs and against the committed golden fixtures.
+
+Bars: bit-exact for integer work (CSR construction, BFS levels, triangle counts);
+PageRank within 1e-6 relative of the fp64 CPU result with the same iteration count
+(BASELINE.json north_star), fp64 mode within 1e-12."""
+import numpy as np
+import pytest
+
+import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+INT_MAX = 2147483647
+PR_RTOL_F32 = 1e-6      # north_star: "PageRank ranks match within 1e-6 relative"
+PR_RTOL_F64 = 1e-12
+
+
+@pytest.fixture(scope="module")
+def gmx():
+    import gmx as m
+    m.require_device()
+    return m
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a.astype(np.float64) - b) / np.abs(b)))
+
+
+def host_graphs(golden):
+    out = []
+    for name, c in golden["cases"].items():
+        man = golden["manifest"]["hand"].get(name[5:]) if name.startswith("hand_") else golden["manifest"]["rmat"][name]
+        out.append((name, c, man))
+    return out
+
+
+def test_device_is_gfx950(gmx):
+    info = gmx.device_info()
+    assert info["arch"].startswith("gfx950"), info
+
+
+def test_rmat_generator_bit_compatible(gmx, golden):
+    """gmx_graph_create_rmat == reference create_RMAT_graph + do_semi_sort + make_reverse_edges."""
+    for name, m in golden["manifest"]["rmat"].items():
+        if m["N"] > (1 << 14):
+            continue
+        g = gmx.Graph.rmat(m["N"], m["M"], m["seed"], *m["abc"], permute=m["permute"])
+        begin, node_idx, rb, rn = g.download()
+        if name in golden["cases"]:
+            c = golden["cases"][name]
+            assert np.array_equal(begin, c["begin"]), name
+            assert np.array_equal(node_idx, c["node_idx"]), name
+            assert np.array_equal(rb, c["r_begin"]) and np.array_equal(rn, c["r_node_idx"]), name
+        else:
+            og = po.Graph(m["N"], *po.rmat_raw_csr(m["N"], m["M"], m["seed"], *m["abc"], permute=m["permute"])[:2]).prepare()
+            assert np.array_equal(begin, og.begin) and np.array_equal(node_idx, og.node_idx), name
+            assert np.array_equal(rb, og.r_begin) and np.array_equal(rn, og.r_node_idx), name
+        g.free()
+
+
+def test_upload_builds_reverse_and_sorts(gmx, golden):
+    for name, c, _ in host_graphs(golden):
+        # raw (unsorted) rows, no reverse given: device must do_semi_sort + make_reverse_edges
+        g = gmx.Graph.upload(c["begin"], c["raw_node_idx"], flags=gmx.GMX_GRAPH_SORT_ROWS)
+        begin, node_idx, rb, rn = g.download()
+        assert np.array_equal(begin, c["begin"]) and np.array_equal(node_idx, c["node_idx"]), name
+        assert np.array_equal(rb, c["r_begin"]) and np.array_equal(rn, c["r_node_idx"]), name
+        g.free()
+
+
+def test_pagerank_golden_f64(gmx, golden):
+    for name, c, m in host_graphs(golden):
+        g = gmx.Graph.upload(c["begin"], c["node_idx"], c["r_begin"], c["r_node_idx"])
+        rank, st = g.pagerank(0.001, 0.85, 100, np.float64)
+        assert st["iterations"] == m["pr_iters"], (name, st)
+        assert rel_err(rank, c["rank"]) < PR_RTOL_F64, (name, rel_err(rank, c["rank"]))
+        g.free()
+
+
+def test_pagerank_golden_f32(gmx, golden):
+    for name, c, m in host_graphs(golden):
+        g = gmx.Graph.upload(c["begin"], c["node_idx"], c["r_begin"], c["r_node_idx"])
+        rank, st = g.pagerank(0.001, 0.85, 100, np.float32)
+        assert st["iterations"] == m["pr_iters"], (name, st)
+        assert rel_err(rank, c["rank"]) < PR_RTOL_F32, (name, rel_err(rank, c["rank"]))
+        g.free()
+
+
+@pytest.mark.parametrize("options", [0, 1, 3])
+@pytest.mark.parametrize("elem", [4, 8])
+def test_pagerank_stepping_variants(gmx, golden, options, elem):
+    """Every kernel variant (identity numbering / degree-sorted / LDS hot tile) for 20 fixed iterations."""
+    for name in ("rmat10_noperm", "rmat10_perm", "hand_star64", "hand_multi_edge", "hand_empty1"):
+        c = golden["cases"][name]
+        g = gmx.Graph.upload(c["begin"], c["node_idx"], c["r_begin"], c["r_node_idx"])
+        og = po.Graph(len(c["begin"]) - 1, c["begin"], c["node_idx"], c["r_begin"], c["r_node_idx"])
+        want, _, _ = po.pagerank(og, 1e-300, 0.85, 20)
+        st = gmx.PageRankState(g, elem, 0, 1, options)
+        st.reset(0.85)
+        for _ in range(20):
+            st.step()
+        got = st.download()
+        tol = PR_RTOL_F32 if elem == 4 else PR_RTOL_F64
+        assert rel_err(got, want) < tol, (name, options, elem, rel_err(got, want))
+        st.free()
+        g.free()
+
+
+@pytest.mark.parametrize("scale,permute", [(16, False), (16, True), (18, True)])
+def test_pagerank_vs_oracle_larger(gmx, scale, permute):
+    og = po.rmat_graph(scale, permute=permute)
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    want, it, _ = po.pagerank(og, 0.001, 0.85, 100)
+    r64, st64 = g.pagerank(0.001, 0.85, 100, np.float64)
+    r32, st32 = g.pagerank(0.001, 0.85, 100, np.float32)
+    assert st64["iterations"] == it and st32["iterations"] == it
+    assert rel_err(r64, want) < PR_RTOL_F64
+    assert rel_err(r32, want) < PR_RTOL_F32
+    # run-to-run determinism (no float atomics on the path)
+    r32b, _ = g.pagerank(0.001, 0.85, 100, np.float32)
+    assert np.array_equal(r32, r32b)
+    g.free()
+
+
+def test_hop_dist_golden(gmx, golden):
+    for name, c, m in host_graphs(golden):
+        g = gmx.Graph.upload(c["begin"], c["node_idx"], c["r_begin"], c["r_node_idx"])
+        dist, st = g.hop_dist(m["root"])
+        assert np.array_equal(dist, c["dist"]), name
+        # top-down only (no reverse CSR on the device)
+        g2 = gmx.Graph.upload(c["begin"], c["node_idx"], flags=gmx.GMX_GRAPH_NO_REVERSE)
+        dist2, _ = g2.hop_dist(m["root"])
+        assert np.array_equal(dist2, c["dist"]), name
+        g.free()
+        g2.free()
+
+
+@pytest.mark.parametrize("scale,permute", [(16, False), (18, False), (18, True), (20, False)])
+def test_hop_dist_vs_oracle_larger(gmx, scale, permute):
+    og = po.rmat_graph(scale, permute=permute)
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    for root in (0, int(np.argmax(np.diff(og.begin))), og.N - 1):
+        want = po.bfs_queue(og, root)
+        dist, st = g.hop_dist(root)
+        assert np.array_equal(dist, want), (scale, permute, root)
+        assert st["vertices_reached"] == int((want != INT_MAX).sum())
+    g.free()
+
+
+def test_hop_dist_bad_root(gmx, golden):
+    c = golden["cases"]["rmat6_noperm"]
+    g = gmx.Graph.upload(c["begin"], c["node_idx"], c["r_begin"], c["r_node_idx"])
+    dist, _ = g.hop_dist(-1)
+    assert (dist == INT_MAX).all()
+    g.free()
+
+
+def test_triangle_counting_golden(gmx, golden):
+    for name, c, m in host_graphs(golden):
+        want = m["tc"] if "tc" in m else m["tc_directed"]
+        g = gmx.Graph.upload(c["begin"], c["node_idx"], c["r_begin"], c["r_node_idx"])
+        T, _ = g.triangle_counting()
+        assert T == want, (name, T, want)
+        g2 = gmx.Graph.upload(c["begin"], c["node_idx"], flags=gmx.GMX_GRAPH_NO_REVERSE)
+        T2, _ = g2.triangle_counting()
+        assert T2 == want, (name, "forward-only", T2, want)
+        g.free()
+        g2.free()
+
+
+@pytest.mark.parametrize("name", ["rmat12_noperm", "rmat14_noperm", "rmat14_perm", "rmat16_noperm"])
+def test_triangle_counting_manifest(gmx, golden, name):
+    m = golden["manifest"]["rmat"][name]
+    og = po.Graph(m["N"], *po.rmat_raw_csr(m["N"], m["M"], m["seed"], *m["abc"], permute=m["permute"])[:2]).prepare()
+    if m["tc_directed"] is not None:
+        g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+        assert g.triangle_counting()[0] == m["tc_directed"]
+        g.free()
+    gs = po.symmetrize(og)
+    g = gmx.Graph.upload(gs.begin, gs.node_idx, gs.r_begin, gs.r_node_idx)
+    assert g.triangle_counting()[0] == m["tc_symmetrized"]
+    g.free()
+
+
+def test_from_edges_matches_oracle(gmx):
+    rng = np.random.default_rng(5)
+    V, E = 1000, 20000
+    src = rng.integers(0, V, E).astype(np.int32)
+    dst = rng.integers(0, V, E).astype(np.int32)
+    og = po.graph_from_edges(V, src, dst)
+    g = gmx.Graph.from_edges(V, src, dst)
+    begin, node_idx, rb, rn = g.download()
+    assert np.array_equal(begin, og.begin) and np.array_equal(node_idx, og.node_idx)
+    assert np.array_equal(rb, og.r_begin) and np.array_equal(rn, og.r_node_idx)
+    g.free()
