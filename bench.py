@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: edges/s (GTEPS) per PageRank iteration on RMAT-26.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one PageRank iteration (pagerank.gm:9-19 loop body) of the WHOLE job: the local
+neighbour-reduction sweep of every rank plus, for N > 1, the all-gather of the new contribution
+slices.  Inputs (CSR, rank and contribution vectors) are resident in HBM before the timed region.
+The graph is the reference's own RMAT generator (graph_gen.cc:159-287, seed 1997, a,b,c =
+.57,.19,.19, edge factor 16, permute=true) run on the device, then do_semi_sort +
+make_reverse_edges exactly as load_binary does.  Total work is fixed as N grows ("strong").
+
+Rank 0 prints ONE JSON line with the driver's contract fields plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "green-marl_amd"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def cpu_baseline(gmx, scale, iters):
+    """The oracle's OpenMP restatement of the emitted pagerank (kind "port"), timed on this box's
+    host cores on a bounded sample of the same workload.  The checker is only TIMED here; nothing
+    it computes feeds the GPU path."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    g = gmx.Graph.rmat(1 << scale, 16 << scale, 1997, 0.57, 0.19, 0.19, True)
+    begin, node_idx, rb, rn = g.download()
+    g.free()
+    og = po.Graph(1 << scale, begin, node_idx, rb, rn)
+    cores = po.lib().gmo_max_threads()
+    po.pagerank(og, 1e-300, 0.85, 1, nthreads=cores)     # touch pages / warm up
+    t0 = time.perf_counter()
+    _, it, _ = po.pagerank(og, 1e-300, 0.85, iters, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": og.M * it / dt / 1e9, "unit": "GTEPS", "cores": cores, "kind": "port",
+            "sample": "RMAT-%d (same generator, seed, permute), %d iterations of the fp64 OpenMP restatement "
+                      "of the emitted pagerank loop (schedule(dynamic,128)), %.1f s" % (scale, it, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scale", type=int, default=26)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--options", type=int, default=-1, help="gmx_pr_create option bits (default: library default)")
+    ap.add_argument("--cpu-scale", type=int, default=24)
+    ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run); got %d"
+                         % (args.gpus, args.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+
+    import gmx
+    from dist_pagerank import DistPageRank, GmxEngine
+
+    gmx.require_device()                       # no CPU fallback: fail loudly without the HIP path
+    torch.cuda.set_device(local_rank)
+    gmx.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    elem = 4 if args.dtype == "f32" else 8
+    options = gmx.GMX_PR_RELABEL if args.options < 0 else args.options
+    N, M = 1 << args.scale, 16 << args.scale
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(gmx, args.cpu_scale, args.cpu_iters)
+
+    t0 = time.perf_counter()
+    graph = gmx.Graph.rmat(N, M, 1997, 0.57, 0.19, 0.19, True)
+    engine = GmxEngine(gmx, graph, elem, rank, world, options)
+    pr = DistPageRank(engine)
+    pr.reset(0.85)
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t0
+
+    for _ in range(args.warmup):
+        pr.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    engine.state.timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pr.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    launches, kernel_ms = engine.state.kernel_time()
+    engine.state.timing(False)
+    last_diff = pr.diff()
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt * 1e3 / args.steps
+    work = engine.state.work()
+    gteps = graph.E / (ms_per_step * 1e-3) / 1e9
+    achieved = work["algorithmic_bytes"] / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+
+    if rank == 0:
+        out = {
+            "metric": "edges/s (GTEPS) per PageRank iter, RMAT-%d" % args.scale,
+            "value": gteps, "unit": "GTEPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "pagerank RMAT-%d (V=%d, E=%d), reference RMAT generator seed 1997 permute=1, "
+                                   "d=0.85, fixed iterations" % (args.scale, N, M),
+                       "partition": "1-D vertex, %d rank(s), all-gather of contribution slices" % world,
+                       "options": options, "setup_s": round(setup_s, 2), "last_diff": last_diff},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": engine.state.kernel_name(), "kernel_ms": kernel_ms, "launches": launches,
+                         "algorithmic_bytes_per_launch": work["algorithmic_bytes"]},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -29,6 +29,29 @@
 
 struct pr_blk { int32_t r, e; };  // merge-path start of a workgroup: local row index, local edge index
 
+#define PR_MAX_SLICES 8
+#define PR_COMBINE_GRID 4096
+#define PR_RUN_SHIFT 11         // sliced numbering: a slice owns runs of 2^11 consecutive ids (all L2 channels)
+
+// Per-slice device arrays of the XCD-sliced variant: slice s holds the in-edges whose SOURCE
+// lies in slice s of the contribution vector, slice(id) = (id >> PR_RUN_SHIFT) % ns (runs of 2048 ids, so a
+// slice spreads over every L2 channel and no cache line is shared between slices).  Workgroups running on XCD x pull work for slice x % ns, so each
+// XCD's private L2 only ever caches 1/ns of the vector.
+struct pr_slice_desc {
+    const pr_blk* blk;
+    int64_t nblk;
+    const int32_t* rb;
+    const int32_t* ridx;
+    double* part_first;
+    double* part_last;
+    void* partial;   // [rows] row sums restricted to this slice (element type S)
+};
+struct pr_sliced_args {
+    pr_slice_desc s[PR_MAX_SLICES];
+    int ns;
+    unsigned int* queue;   // [ns] next unclaimed merge-path block of each slice
+};
+
 struct gmx_pr {
     gmx_graph* g = nullptr;
     int elem = 4;
@@ -37,7 +60,8 @@ struct gmx_pr {
     int64_t V = 0;        // vertices of the whole graph
     int64_t slice = 0;    // rows per rank (Vpad / nranks)
     int64_t Vpad = 0;     // slice * nranks, size of the contribution replica
-    int64_t rows = 0;     // real rows owned by this rank (<= slice)
+    int64_t rows = 0;     // local row ids of this rank (sliced: includes padding rows, outdeg -1)
+    int64_t rows_real = 0;  // vertices owned by this rank
     int64_t row_lo = 0;   // first owned row in the internal numbering
     int64_t El = 0;       // edges of the owned rows
     dbuf<int32_t> inv;    // internal id -> original id for owned rows [rows]
@@ -58,7 +82,40 @@ struct gmx_pr {
     dbuf<double> diff;    // [1]
     double d = 0.85;
     int32_t cnt = 0;
+    // XCD-sliced variant
+    int ns = 0;
+    pr_sliced_args sl;
+    dbuf<int32_t> sl_rb, sl_ridx;
+    dbuf<pr_blk> sl_blk;
+    dbuf<double> sl_part_first, sl_part_last;
+    dbuf<char> sl_partial;
+    dbuf<unsigned int> sl_queue;
+    int64_t sl_nblk_total = 0;
+    // dominant-kernel timing (hipEvents on the launch stream)
+    bool timing = false;
+    std::vector<hipEvent_t> ev;   // pairs
+    int ev_used = 0;
+    ~gmx_pr() {
+        for (hipEvent_t e : ev) (void) hipEventDestroy(e);
+    }
 };
+
+#define PR_MAX_TIMED 256
+static inline void pr_ev_begin(gmx_pr* p, hipStream_t s) {
+    if (!p->timing || p->ev_used >= PR_MAX_TIMED) return;
+    if ((int) p->ev.size() < 2 * (p->ev_used + 1)) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        p->ev.push_back(a);
+        p->ev.push_back(b);
+    }
+    (void) hipEventRecord(p->ev[2 * p->ev_used], s);
+}
+static inline void pr_ev_end(gmx_pr* p, hipStream_t s) {
+    if (!p->timing || p->ev_used >= PR_MAX_TIMED || (int) p->ev.size() < 2 * (p->ev_used + 1)) return;
+    (void) hipEventRecord(p->ev[2 * p->ev_used + 1], s);
+    p->ev_used++;
+}
 
 static int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
     int64_t b = (n + block - 1) / block;
@@ -79,13 +136,21 @@ __global__ void pr_degkey_kernel(const int32_t* __restrict__ begin, int64_t V,
 }
 
 // order[j] = original id of the j-th hottest vertex (NULL: identity); deal positions to ranks.
-__global__ void pr_perm_kernel(const int32_t* __restrict__ order, int64_t V, int64_t slice, int nranks,
+// ns > 0 (XCD-sliced): inside a rank, hotness position q is dealt to slice q % ns and the slices
+// are laid out as interleaved runs of 2^PR_RUN_SHIFT ids, so every slice gets the same share
+// of hot vertices and its ids stay dense.
+__global__ void pr_perm_kernel(const int32_t* __restrict__ order, int64_t V, int64_t slice, int nranks, int ns,
                                int32_t* __restrict__ perm) {
     int64_t j = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t) gridDim.x * blockDim.x;
     for (; j < V; j += stride) {
-        if (order) perm[order[j]] = (int32_t) ((j % nranks) * slice + j / nranks);
-        else perm[j] = (int32_t) j;
+        if (!order) { perm[j] = (int32_t) j; continue; }
+        int64_t l = j / nranks;
+        if (ns > 0) {
+            const int64_t sl = l % ns, q = l / ns, run = (int64_t) 1 << PR_RUN_SHIFT;
+            l = ((q >> PR_RUN_SHIFT) * ns + sl) * run + (q & (run - 1));
+        }
+        perm[order[j]] = (int32_t) ((j % nranks) * slice + l);
     }
 }
 
@@ -131,6 +196,44 @@ __global__ void pr_key_bound_kernel(const uint64_t* __restrict__ keys, int64_t E
     out[threadIdx.x] = lo;
 }
 
+// ---- XCD-sliced plan: slice(src') = (src' >> 5) % ns ----
+__global__ void pr_slice_key_kernel(const uint64_t* __restrict__ keys, int64_t n, int ns, uint8_t* __restrict__ sl) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) sl[i] = (uint8_t) ((((uint32_t) keys[i]) >> PR_RUN_SHIFT) % (uint32_t) ns);
+}
+
+__global__ void pr_slice_offsets_kernel(const uint8_t* __restrict__ sl_sorted, int64_t n, int ns, int64_t* __restrict__ off) {
+    int t = threadIdx.x;
+    if (blockIdx.x || t > ns) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((int) sl_sorted[mid] < t) lo = mid + 1; else hi = mid;
+    }
+    off[t] = lo;
+}
+
+// vals = keys grouped by slice (stable), off[s] = start of slice s.  blockIdx.y = slice.
+__global__ void pr_slice_csr_kernel(const uint64_t* __restrict__ vals, const int64_t* __restrict__ off,
+                                    int64_t row_lo, int64_t rows, int32_t* __restrict__ rb_all, int32_t* __restrict__ ridx_all) {
+    const int sl = blockIdx.y;
+    const int64_t o0 = off[sl], o1 = off[sl + 1];
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (int64_t e = o0 + i; e < o1; e += stride) ridx_all[e] = (int32_t) (uint32_t) (vals[e] & 0xffffffffu);
+    int32_t* rb = rb_all + (int64_t) sl * (rows + 1);
+    for (int64_t r = i; r <= rows; r += stride) {
+        uint64_t target = (uint64_t) (row_lo + r) << 32;
+        int64_t lo = o0, hi = o1;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (vals[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        rb[r] = (int32_t) (lo - o0);
+    }
+}
+
 // merge-path split (Merrill & Garland): diagonal k*items over (row ends, edge indices)
 __global__ void pr_blocks_kernel(const int32_t* __restrict__ rb, int64_t rows, int64_t El, int items,
                                  int64_t nblk, pr_blk* __restrict__ blk) {
@@ -154,12 +257,13 @@ template <typename S>
 __device__ __forceinline__ void pr_finalize(int64_t r, double sum, double base, double d,
                                             S* __restrict__ rk, const int32_t* __restrict__ outdeg,
                                             S* __restrict__ contrib_next_owned, double& diff_acc) {
+    const int32_t od = outdeg[r];
+    if (od < 0) return;   // padding row of the sliced numbering: no vertex lives here
     double val = base + d * sum;
     double old = (double) rk[r];
     S vs = (S) val;
     diff_acc += fabs((double) vs - old);
     rk[r] = vs;
-    int32_t od = outdeg[r];
     contrib_next_owned[r] = od > 0 ? (S) ((double) vs / (double) od) : (S) 0;
 }
 
@@ -169,10 +273,142 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// THREADS threads, ITEMS merge-path items per workgroup pass.  HOT > 0: contributions of the
-// HOT hottest vertices (internal ids 0..HOT-1) are staged in LDS once per workgroup and the
-// workgroup walks the block list persistently.  NT: non-temporal loads for the index stream.
-template <typename S, int THREADS, int ITEMS, int HOT, bool NT>
+// Output policies of the row reduction: either apply the PageRank update directly, or leave
+// the per-slice row sum for the combine pass.
+template <typename S>
+struct out_final {
+    S* rk;
+    const int32_t* outdeg;
+    S* next_owned;
+    double base, d;
+    double* part_first;
+    double* part_last;
+    __device__ __forceinline__ void row(int64_t r, double sum, double& diff_acc) const {
+        pr_finalize<S>(r, sum, base, d, rk, outdeg, next_owned, diff_acc);
+    }
+};
+template <typename S>
+struct out_partial {
+    S* partial;
+    double* part_first;
+    double* part_last;
+    __device__ __forceinline__ void row(int64_t r, double sum, double&) const { partial[r] = (S) sum; }
+};
+
+template <typename S, int ITEMS>
+struct pr_smem {
+    S val[ITEMS];
+    int32_t rb[ITEMS + 2];
+    int32_t longrows[ITEMS / PR_LONG + 2];
+    int32_t nlong;
+};
+
+// One merge-path block: ITEMS path items starting at blk[k].  HOT > 0: contributions of the
+// HOT hottest vertices (internal ids 0..HOT-1) are read from s_hot (LDS).  NT: non-temporal
+// loads for the index stream.  Returns this thread's |val-rank| partial through diff_acc.
+template <typename S, int THREADS, int ITEMS, int HOT, bool NT, typename OUT, int ABL = 0>
+__device__ __forceinline__ void pr_block_body(pr_smem<S, ITEMS>& sm, const S* s_hot,
+                                              const pr_blk* __restrict__ blk, int64_t k, int64_t rows,
+                                              const int32_t* __restrict__ rb, const int32_t* __restrict__ ridx,
+                                              const S* __restrict__ contrib, const OUT& out, double& diff_acc) {
+    constexpr int PER = ITEMS / THREADS;
+    constexpr int NW = THREADS / 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const pr_blk b0 = blk[k], b1 = blk[k + 1];
+    const int r0 = b0.r, e0 = b0.e, r1 = b1.r, e1 = b1.e;
+    const int ne = e1 - e0;
+    const int nr = r1 - r0 + 1;  // rows touched; the last one (r1) does not finish here
+
+    __syncthreads();  // previous pass done with LDS (and s_hot visible)
+    if (tid == 0) sm.nlong = 0;
+    for (int i = tid; i < nr; i += THREADS) sm.rb[i] = rb[r0 + i];   // r1 <= rows, rb has rows+1 entries
+
+    // ---- gather: coalesced index stream, random contribution reads, staged in LDS ----
+    {
+        int32_t ix[PER];
+        S vv[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            int j = tid + u * THREADS;
+            ix[u] = -1;
+            if (j < ne) ix[u] = NT ? __builtin_nontemporal_load(ridx + e0 + j) : ridx[e0 + j];
+        }
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            vv[u] = (S) 0;
+            if (ix[u] >= 0) {
+                if (ABL == 1) vv[u] = (S) 1;                        // ablation: no gather
+                else if (ABL == 2) vv[u] = contrib[ix[u] & 1023];     // ablation: L1-resident gather
+                else if (HOT > 0 && ix[u] < HOT) vv[u] = s_hot[ix[u]];
+                else vv[u] = contrib[ix[u]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            int j = tid + u * THREADS;
+            if (j < ne) sm.val[j] = vv[u];
+        }
+    }
+    __syncthreads();
+
+    const bool first_started_here = (sm.rb[0] >= e0);   // rb[r0] == e0
+    // ---- short rows: one thread per row, sequential fp64 sum in edge order ----
+    for (int i = tid; i < nr; i += THREADS) {
+        int lo = sm.rb[i] - e0;
+        if (lo < 0) lo = 0;
+        int hi = (i < nr - 1) ? sm.rb[i + 1] - e0 : ne;
+        if (hi - lo > PR_LONG) {
+            int q = atomicAdd(&sm.nlong, 1);
+            sm.longrows[q] = i;
+            continue;
+        }
+        double sum = 0.0;
+        for (int j = lo; j < hi; j++) sum += (double) sm.val[j];
+        const bool started = (i > 0) || first_started_here;
+        const bool finished = (i < nr - 1);
+        if (!started) out.part_first[k] = sum;
+        else if (finished) out.row((int64_t) r0 + i, sum, diff_acc);
+        else if (r0 + i < rows && hi > lo) out.part_last[k] = sum;
+    }
+    __syncthreads();
+    // ---- long rows: one wave per row, strided fp64 partials + shuffle reduction ----
+    const int nlong = sm.nlong;
+    for (int q = wave; q < nlong; q += NW) {
+        const int i = sm.longrows[q];
+        int lo = sm.rb[i] - e0;
+        if (lo < 0) lo = 0;
+        const int hi = (i < nr - 1) ? sm.rb[i + 1] - e0 : ne;
+        double sum = 0.0;
+        for (int j = lo + lane; j < hi; j += 64) sum += (double) sm.val[j];
+        sum = wave_sum(sum);
+        if (lane == 0) {
+            const bool started = (i > 0) || first_started_here;
+            const bool finished = (i < nr - 1);
+            if (!started) out.part_first[k] = sum;
+            else if (finished) out.row((int64_t) r0 + i, sum, diff_acc);
+            else if (r0 + i < rows) out.part_last[k] = sum;
+        }
+    }
+}
+
+template <int THREADS>
+__device__ __forceinline__ void pr_block_diff(double diff_acc, double* s_red, double* __restrict__ dst) {
+    constexpr int NW = THREADS / 64;
+    const int tid = threadIdx.x;
+    diff_acc = wave_sum(diff_acc);
+    if ((tid & 63) == 0) s_red[tid >> 6] = diff_acc;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) t += s_red[w];
+        *dst = t;
+    }
+}
+
+// Plain variant: block k of the grid (or a persistent walk when HOT > 0) updates ranks in place.
+template <typename S, int THREADS, int ITEMS, int HOT, bool NT, int ABL = 0>
 __global__ void __launch_bounds__(THREADS)
 pr_step_kernel(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
                const int32_t* __restrict__ rb, const int32_t* __restrict__ ridx,
@@ -180,136 +416,122 @@ pr_step_kernel(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
                const S* __restrict__ contrib, S* __restrict__ contrib_next_owned,
                double base, double d,
                double* __restrict__ part_first, double* __restrict__ part_last, double* __restrict__ diff_part) {
-    constexpr int PER = ITEMS / THREADS;
-    constexpr int NW = THREADS / 64;
-    __shared__ S s_val[ITEMS];
-    __shared__ int32_t s_rb[ITEMS + 2];
-    __shared__ int32_t s_long[ITEMS / PR_LONG + 2];
-    __shared__ int32_t s_nlong;
-    __shared__ double s_red[NW];
+    __shared__ pr_smem<S, ITEMS> sm;
+    __shared__ double s_red[THREADS / 64];
     __shared__ S s_hot[HOT > 0 ? HOT : 1];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-
     if (HOT > 0) {
-        for (int i = tid; i < HOT; i += THREADS) s_hot[i] = contrib[i];
+        for (int i = threadIdx.x; i < HOT; i += THREADS) s_hot[i] = contrib[i];
     }
-
+    out_final<S> out{rk, outdeg, contrib_next_owned, base, d, part_first, part_last};
     for (int64_t k = blockIdx.x; k < nblk; k += gridDim.x) {
-        const pr_blk b0 = blk[k], b1 = blk[k + 1];
-        const int r0 = b0.r, e0 = b0.e, r1 = b1.r, e1 = b1.e;
-        const int ne = e1 - e0;
-        const int nr = r1 - r0 + 1;  // rows touched; the last one (r1) does not finish here
         double diff_acc = 0.0;
+        pr_block_body<S, THREADS, ITEMS, HOT, NT, out_final<S>, ABL>(sm, s_hot, blk, k, rows, rb, ridx, contrib, out, diff_acc);
+        pr_block_diff<THREADS>(diff_acc, s_red, diff_part + k);
+    }
+}
 
-        __syncthreads();  // previous pass done with LDS (and s_hot visible)
-        if (tid == 0) s_nlong = 0;
-        for (int i = tid; i < nr; i += THREADS) s_rb[i] = rb[r0 + i];   // r1 <= rows, rb has rows+1 entries
+__device__ __forceinline__ int pr_xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return (int) (v & 0xf);
+}
 
-        // ---- gather: coalesced index stream, random contribution reads, staged in LDS ----
-        {
-            int32_t ix[PER];
-            S vv[PER];
-#pragma unroll
-            for (int u = 0; u < PER; u++) {
-                int j = tid + u * THREADS;
-                ix[u] = -1;
-                if (j < ne) ix[u] = NT ? __builtin_nontemporal_load(ridx + e0 + j) : ridx[e0 + j];
+// XCD-sliced variant: persistent workgroups; a workgroup on XCD x claims merge-path blocks of
+// slice x % ns from a queue (and steals from the other slices once its own is drained, which
+// only costs locality).  Row sums go to partial[slice][row]; pr_combine_kernel adds the slices.
+template <typename S, int THREADS, int ITEMS, bool NT>
+__global__ void __launch_bounds__(THREADS)
+pr_sliced_kernel(pr_sliced_args a, int64_t rows, const S* __restrict__ contrib) {
+    __shared__ pr_smem<S, ITEMS> sm;
+    __shared__ long long s_k;
+    __shared__ int s_sl;
+    const int home = pr_xcc_id() % a.ns;
+    int first_try = 0;   // slices before this offset are known to be drained
+    for (;;) {
+        if (threadIdx.x == 0) {
+            long long k = -1;
+            int sl = home;
+            for (int t = first_try; t < a.ns; t++) {
+                sl = (home + t) % a.ns;
+                unsigned int kk = atomicAdd(&a.queue[sl], 1u);
+                if ((int64_t) kk < a.s[sl].nblk) { k = (long long) kk; first_try = t; break; }
+                first_try = t + 1;
             }
-#pragma unroll
-            for (int u = 0; u < PER; u++) {
-                vv[u] = (S) 0;
-                if (ix[u] >= 0) {
-                    if (HOT > 0 && ix[u] < HOT) vv[u] = s_hot[ix[u]];
-                    else vv[u] = contrib[ix[u]];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < PER; u++) {
-                int j = tid + u * THREADS;
-                if (j < ne) s_val[j] = vv[u];
-            }
+            s_k = k;
+            s_sl = sl;
         }
         __syncthreads();
-
-        const bool first_started_here = (s_rb[0] >= e0);   // rb[r0] == e0
-        // ---- short rows: one thread per row, sequential fp64 sum in edge order ----
-        for (int i = tid; i < nr; i += THREADS) {
-            int lo = s_rb[i] - e0;
-            if (lo < 0) lo = 0;
-            int hi = (i < nr - 1) ? s_rb[i + 1] - e0 : ne;
-            if (hi - lo > PR_LONG) {
-                int q = atomicAdd(&s_nlong, 1);
-                s_long[q] = i;
-                continue;
-            }
-            double sum = 0.0;
-            for (int j = lo; j < hi; j++) sum += (double) s_val[j];
-            const bool started = (i > 0) || first_started_here;
-            const bool finished = (i < nr - 1);
-            if (!started) part_first[k] = sum;
-            else if (finished) pr_finalize<S>((int64_t) r0 + i, sum, base, d, rk, outdeg, contrib_next_owned, diff_acc);
-            else if (r0 + i < rows && hi > lo) part_last[k] = sum;
-        }
-        __syncthreads();
-        // ---- long rows: one wave per row, strided fp64 partials + shuffle reduction ----
-        const int nlong = s_nlong;
-        for (int q = wave; q < nlong; q += NW) {
-            // the list was filled in arbitrary order; each entry is handled independently
-            const int i = s_long[q];
-            int lo = s_rb[i] - e0;
-            if (lo < 0) lo = 0;
-            const int hi = (i < nr - 1) ? s_rb[i + 1] - e0 : ne;
-            double sum = 0.0;
-            for (int j = lo + lane; j < hi; j += 64) sum += (double) s_val[j];
-            sum = wave_sum(sum);
-            if (lane == 0) {
-                const bool started = (i > 0) || first_started_here;
-                const bool finished = (i < nr - 1);
-                if (!started) part_first[k] = sum;
-                else if (finished) pr_finalize<S>((int64_t) r0 + i, sum, base, d, rk, outdeg, contrib_next_owned, diff_acc);
-                else if (r0 + i < rows) part_last[k] = sum;
-            }
-        }
-        // ---- |val - rank| partial of this workgroup pass ----
-        diff_acc = wave_sum(diff_acc);
-        if (lane == 0) s_red[wave] = diff_acc;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
-#pragma unroll
-            for (int w = 0; w < NW; w++) t += s_red[w];
-            diff_part[k] = t;
-        }
+        const long long k = s_k;
+        const int sl = s_sl;
+        if (k < 0) break;
+        const pr_slice_desc& sd = a.s[sl];
+        out_partial<S> out{(S*) sd.partial, sd.part_first, sd.part_last};
+        double diff_acc = 0.0;
+        pr_block_body<S, THREADS, ITEMS, 0, NT>(sm, (const S*) nullptr, sd.blk, (int64_t) k, rows, sd.rb, sd.ridx, contrib, out, diff_acc);
+        __syncthreads();   // s_k / s_sl are rewritten by thread 0 at the top
     }
 }
 
 // Rows that span workgroups: the workgroup that OPENED row r (r == blk[k+1].r, rb[r] in
 // [e0,e1)) left part_last[k]; every later workgroup touching r left part_first[k'].
-template <typename S>
-__global__ void pr_fixup_kernel(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
-                                const int32_t* __restrict__ rb, const int32_t* __restrict__ outdeg,
-                                S* __restrict__ rk, S* __restrict__ contrib_next_owned, double base, double d,
-                                const double* __restrict__ part_first, const double* __restrict__ part_last,
-                                double* __restrict__ diff_fix) {
-    int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nblk) return;
-    double diff_acc = 0.0;
+template <typename S, typename OUT>
+__device__ __forceinline__ void pr_fixup_one(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
+                                             const int32_t* __restrict__ rb, int64_t k, const OUT& out, double& diff_acc) {
     const pr_blk b0 = blk[k], b1 = blk[k + 1];
     const int64_t r = b1.r;
     if (r < rows) {
         const int32_t rs = rb[r];
         if (rs >= b0.e && rs < b1.e) {
-            double total = part_last[k];
+            double total = out.part_last[k];
             for (int64_t kk = k + 1; kk < nblk; kk++) {
-                total += part_first[kk];
+                total += out.part_first[kk];
                 if (blk[kk + 1].r > r) break;
             }
-            pr_finalize<S>(r, total, base, d, rk, outdeg, contrib_next_owned, diff_acc);
+            out.row(r, total, diff_acc);
         }
     }
+}
+
+template <typename S>
+__global__ void pr_fixup_kernel(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
+                                const int32_t* __restrict__ rb, const int32_t* __restrict__ outdeg,
+                                S* __restrict__ rk, S* __restrict__ contrib_next_owned, double base, double d,
+                                double* __restrict__ part_first, double* __restrict__ part_last,
+                                double* __restrict__ diff_fix) {
+    int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nblk) return;
+    double diff_acc = 0.0;
+    out_final<S> out{rk, outdeg, contrib_next_owned, base, d, part_first, part_last};
+    pr_fixup_one<S>(blk, nblk, rows, rb, k, out, diff_acc);
     diff_fix[k] = diff_acc;
+}
+
+template <typename S>
+__global__ void pr_sliced_fixup_kernel(pr_sliced_args a, int64_t rows) {
+    const int sl = blockIdx.y;
+    const pr_slice_desc& sd = a.s[sl];
+    int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= sd.nblk) return;
+    double unused = 0.0;
+    out_partial<S> out{(S*) sd.partial, sd.part_first, sd.part_last};
+    pr_fixup_one<S>(sd.blk, sd.nblk, rows, sd.rb, k, out, unused);
+}
+
+// sum the slices in fixed order and apply the PageRank update (streaming, one thread per row)
+template <typename S>
+__global__ void __launch_bounds__(256)
+pr_combine_kernel(pr_sliced_args a, int64_t rows, const int32_t* __restrict__ outdeg, S* __restrict__ rk,
+                  S* __restrict__ contrib_next_owned, double base, double d, double* __restrict__ diff_part) {
+    __shared__ double s_red[256 / 64];
+    double diff_acc = 0.0;
+    int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; r < rows; r += stride) {
+        double sum = 0.0;
+        for (int sl = 0; sl < a.ns; sl++) sum += (double) __builtin_nontemporal_load((const S*) a.s[sl].partial + r);
+        pr_finalize<S>(r, sum, base, d, rk, outdeg, contrib_next_owned, diff_acc);
+    }
+    pr_block_diff<256>(diff_acc, s_red, diff_part + blockIdx.x);
 }
 
 __global__ void pr_diff_reduce_kernel(const double* __restrict__ part, int64_t n, double* __restrict__ out) {
@@ -332,9 +554,9 @@ __global__ void pr_reset_kernel(int64_t rows, double N, const int32_t* __restric
     int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t) gridDim.x * blockDim.x;
     for (; i < rows; i += stride) {
-        S r0 = (S) (1 / N);                       // G.pg_rank = 1 / N
-        rk[i] = r0;
         int32_t od = outdeg[i];
+        S r0 = od < 0 ? (S) 0 : (S) (1 / N);      // G.pg_rank = 1 / N   (od < 0: padding row)
+        rk[i] = r0;
         contrib_owned[i] = od > 0 ? (S) ((double) r0 / (double) od) : (S) 0;
     }
 }
@@ -344,7 +566,8 @@ __global__ void pr_unpermute_kernel(int64_t rows, const int32_t* __restrict__ in
                                     S* __restrict__ out_orig) {
     int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t) gridDim.x * blockDim.x;
-    for (; i < rows; i += stride) out_orig[inv[i]] = rk[i];
+    for (; i < rows; i += stride)
+        if (inv[i] >= 0) out_orig[inv[i]] = rk[i];
 }
 
 // ------------------------------------------------------------------ plan
@@ -362,18 +585,33 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
     p->nranks = nranks;
     p->options = options;
     p->V = g->V;
+    const bool relabel = (options & GMX_PR_RELABEL) != 0;
+    if ((options & GMX_PR_SLICED) && relabel) {
+        p->ns = PR_MAX_SLICES;
+        const char* ev = getenv("GMX_PR_SLICES");
+        if (ev && atoi(ev) >= 1 && atoi(ev) <= PR_MAX_SLICES) p->ns = atoi(ev);
+    }
     p->slice = (g->V + nranks - 1) / nranks;
     if (p->slice < 1) p->slice = 1;
+    if (p->ns > 0) {   // whole runs for every slice
+        const int64_t unit = (int64_t) p->ns << PR_RUN_SHIFT;
+        p->slice = (p->slice + unit - 1) / unit * unit;
+    }
     p->Vpad = p->slice * nranks;
+    if (p->Vpad >= (1LL << 31)) {
+        gmx_set_error("padded vertex count %lld exceeds int32", (long long) p->Vpad);
+        delete p;
+        return GMX_ERR_ARG;
+    }
     p->row_lo = (int64_t) rank * p->slice;
-    const bool relabel = (options & GMX_PR_RELABEL) != 0;
-    if (relabel) p->rows = g->V > rank ? (g->V - rank + nranks - 1) / nranks : 0;
+    if (relabel) p->rows_real = g->V > rank ? (g->V - rank + nranks - 1) / nranks : 0;
     else {
         int64_t hi = (int64_t) (rank + 1) * p->slice;
         if (hi > g->V) hi = g->V;
-        p->rows = hi > p->row_lo ? hi - p->row_lo : 0;
+        p->rows_real = hi > p->row_lo ? hi - p->row_lo : 0;
     }
-    p->hot = (options & GMX_PR_HOT_LDS) != 0 && relabel && nranks == 1;
+    p->rows = p->ns > 0 ? p->slice : p->rows_real;
+    p->hot = (options & GMX_PR_HOT_LDS) != 0 && relabel && nranks == 1 && p->ns == 0;
     p->threads = p->hot ? 1024 : 256;
     p->items = p->hot ? 4096 : 2048;
 
@@ -382,6 +620,8 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
     int st = GMX_OK;
     do {
         if ((st = p->inv.alloc((size_t) p->rows)) || (st = p->outdeg.alloc((size_t) p->rows))) break;
+        if (p->rows && (hipMemset(p->inv.p, 0xff, sizeof(int32_t) * (size_t) p->rows) != hipSuccess ||
+                        hipMemset(p->outdeg.p, 0xff, sizeof(int32_t) * (size_t) p->rows) != hipSuccess)) { gmx_set_error("pr plan: memset failed"); st = GMX_ERR_HIP; break; }
         if (!relabel && nranks == 1) {
             // identity numbering, whole graph: use the graph's reverse CSR as is
             p->rb = g->r_begin.p;
@@ -389,7 +629,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
             p->El = E;
             dbuf<int32_t> perm;
             if ((st = perm.alloc((size_t) V))) break;
-            hipLaunchKernelGGL(pr_perm_kernel, dim3(grid_for(V)), dim3(256), 0, s, (const int32_t*) nullptr, V, p->slice, nranks, perm.p);
+            hipLaunchKernelGGL(pr_perm_kernel, dim3(grid_for(V)), dim3(256), 0, s, (const int32_t*) nullptr, V, p->slice, nranks, 0, perm.p);
             hipLaunchKernelGGL(pr_owned_kernel, dim3(grid_for(V)), dim3(256), 0, s, perm.p, g->begin.p, V, p->row_lo, p->rows, p->inv.p, p->outdeg.p);
             if (hipStreamSynchronize(s) != hipSuccess) { gmx_set_error("pr plan (identity) failed"); st = GMX_ERR_HIP; break; }
         } else {
@@ -407,12 +647,12 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 if (he == hipSuccess && (st = tmp.alloc(tb))) break;
                 if (he == hipSuccess) he = rocprim::radix_sort_pairs((void*) tmp.p, tb, key.p, key2.p, id.p, order.p, (size_t) V, 0u, 32u, s);
                 if (he == hipSuccess) {
-                    hipLaunchKernelGGL(pr_perm_kernel, dim3(grid_for(V)), dim3(256), 0, s, (const int32_t*) order.p, V, p->slice, nranks, perm.p);
+                    hipLaunchKernelGGL(pr_perm_kernel, dim3(grid_for(V)), dim3(256), 0, s, (const int32_t*) order.p, V, p->slice, nranks, p->ns, perm.p);
                     he = hipStreamSynchronize(s);
                 }
                 if (he != hipSuccess) { gmx_set_error("pr plan: degree sort failed: %s", hipGetErrorString(he)); st = GMX_ERR_HIP; break; }
             } else {
-                hipLaunchKernelGGL(pr_perm_kernel, dim3(grid_for(V)), dim3(256), 0, s, (const int32_t*) nullptr, V, p->slice, nranks, perm.p);
+                hipLaunchKernelGGL(pr_perm_kernel, dim3(grid_for(V)), dim3(256), 0, s, (const int32_t*) nullptr, V, p->slice, nranks, 0, perm.p);
             }
             hipLaunchKernelGGL(pr_owned_kernel, dim3(grid_for(V)), dim3(256), 0, s, perm.p, g->begin.p, V, p->row_lo, p->rows, p->inv.p, p->outdeg.p);
             // keys (perm[dst] << 32 | perm[src]) from the reverse CSR, sorted; then cut the owned rows
@@ -439,19 +679,75 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
             int64_t hb[2] = {0, 0};
             if (hipMemcpy(hb, bounds.p, sizeof(hb), hipMemcpyDeviceToHost) != hipSuccess) { gmx_set_error("pr plan: bounds copy failed"); st = GMX_ERR_HIP; break; }
             p->El = hb[1] - hb[0];
-            if ((st = p->rb_own.alloc((size_t) p->rows + 1)) || (st = p->ridx_own.alloc((size_t) p->El))) break;
-            hipLaunchKernelGGL(pr_local_csr_kernel, dim3(grid_for(p->El > p->rows ? p->El : p->rows + 1)), dim3(256), 0, s,
-                               sorted, E, p->row_lo, p->rows, hb[0], p->El, p->rb_own.p, p->ridx_own.p);
-            if (hipStreamSynchronize(s) != hipSuccess) { gmx_set_error("pr plan: local csr failed"); st = GMX_ERR_HIP; break; }
-            p->rb = p->rb_own.p;
-            p->ridx = p->ridx_own.p;
+            if (p->ns > 0) {
+                // group the owned keys by source slice (stable 1-pass radix sort on the slice number)
+                const int ns = p->ns;
+                const int64_t El = p->El, rows = p->rows;
+                dbuf<uint8_t> sk, sk2;
+                dbuf<uint64_t> vals;
+                dbuf<int64_t> off;
+                if ((st = sk.alloc((size_t) El)) || (st = sk2.alloc((size_t) El)) || (st = vals.alloc((size_t) El)) ||
+                    (st = off.alloc(PR_MAX_SLICES + 1))) break;
+                hipLaunchKernelGGL(pr_slice_key_kernel, dim3(grid_for(El)), dim3(256), 0, s, sorted + hb[0], El, ns, sk.p);
+                hipError_t he = hipSuccess;
+                if (El > 0) {
+                    size_t tb = 0;
+                    he = rocprim::radix_sort_pairs(nullptr, tb, sk.p, sk2.p, sorted + hb[0], vals.p, (size_t) El, 0u, 3u, s);
+                    dbuf<char> tmp;
+                    if (he == hipSuccess && (st = tmp.alloc(tb))) break;
+                    if (he == hipSuccess) he = rocprim::radix_sort_pairs((void*) tmp.p, tb, sk.p, sk2.p, sorted + hb[0], vals.p, (size_t) El, 0u, 3u, s);
+                    if (he == hipSuccess) he = hipStreamSynchronize(s);
+                }
+                if (he != hipSuccess) { gmx_set_error("pr plan: slice sort failed: %s", hipGetErrorString(he)); st = GMX_ERR_HIP; break; }
+                hipLaunchKernelGGL(pr_slice_offsets_kernel, dim3(1), dim3(64), 0, s, (const uint8_t*) sk2.p, El, ns, off.p);
+                int64_t hoff[PR_MAX_SLICES + 1];
+                if (hipMemcpy(hoff, off.p, sizeof(int64_t) * (ns + 1), hipMemcpyDeviceToHost) != hipSuccess) { gmx_set_error("pr plan: slice offsets copy failed"); st = GMX_ERR_HIP; break; }
+                if ((st = p->sl_rb.alloc((size_t) ns * (rows + 1))) || (st = p->sl_ridx.alloc((size_t) El))) break;
+                hipLaunchKernelGGL(pr_slice_csr_kernel, dim3(grid_for((El / ns > rows ? El / ns : rows) + 1), ns), dim3(256), 0, s,
+                                   (const uint64_t*) vals.p, (const int64_t*) off.p, p->row_lo, rows, p->sl_rb.p, p->sl_ridx.p);
+                int64_t nblk_s[PR_MAX_SLICES], blk_off[PR_MAX_SLICES + 1];
+                blk_off[0] = 0;
+                for (int q = 0; q < ns; q++) {
+                    int64_t tot = rows + (hoff[q + 1] - hoff[q]);
+                    nblk_s[q] = (tot + p->items - 1) / p->items;
+                    blk_off[q + 1] = blk_off[q] + nblk_s[q] + 1;
+                }
+                p->sl_nblk_total = blk_off[ns];
+                size_t npart = (size_t) (p->sl_nblk_total ? p->sl_nblk_total : 1);
+                if ((st = p->sl_blk.alloc(npart)) || (st = p->sl_part_first.alloc(npart)) || (st = p->sl_part_last.alloc(npart)) ||
+                    (st = p->sl_partial.alloc((size_t) ns * (rows ? rows : 1) * elem_bytes)) || (st = p->sl_queue.alloc(PR_MAX_SLICES))) break;
+                memset(&p->sl, 0, sizeof(p->sl));
+                p->sl.ns = ns;
+                p->sl.queue = p->sl_queue.p;
+                for (int q = 0; q < ns; q++) {
+                    pr_slice_desc& sd = p->sl.s[q];
+                    sd.blk = p->sl_blk.p + blk_off[q];
+                    sd.nblk = nblk_s[q];
+                    sd.rb = p->sl_rb.p + (int64_t) q * (rows + 1);
+                    sd.ridx = p->sl_ridx.p + hoff[q];
+                    sd.part_first = p->sl_part_first.p + blk_off[q];
+                    sd.part_last = p->sl_part_last.p + blk_off[q];
+                    sd.partial = p->sl_partial.p + (size_t) q * (size_t) rows * elem_bytes;
+                    hipLaunchKernelGGL(pr_blocks_kernel, dim3(grid_for(nblk_s[q] + 1, 256, 1 << 30)), dim3(256), 0, s,
+                                       sd.rb, rows, hoff[q + 1] - hoff[q], p->items, nblk_s[q], p->sl_blk.p + blk_off[q]);
+                }
+                if (hipStreamSynchronize(s) != hipSuccess) { gmx_set_error("pr plan: slice csr failed"); st = GMX_ERR_HIP; break; }
+            } else {
+                if ((st = p->rb_own.alloc((size_t) p->rows + 1)) || (st = p->ridx_own.alloc((size_t) p->El))) break;
+                hipLaunchKernelGGL(pr_local_csr_kernel, dim3(grid_for(p->El > p->rows ? p->El : p->rows + 1)), dim3(256), 0, s,
+                                   sorted, E, p->row_lo, p->rows, hb[0], p->El, p->rb_own.p, p->ridx_own.p);
+                if (hipStreamSynchronize(s) != hipSuccess) { gmx_set_error("pr plan: local csr failed"); st = GMX_ERR_HIP; break; }
+                p->rb = p->rb_own.p;
+                p->ridx = p->ridx_own.p;
+            }
         }
         // merge-path blocks
         int64_t total = p->rows + p->El;
-        p->nblk = (total + p->items - 1) / p->items;
+        p->nblk = p->ns > 0 ? PR_COMBINE_GRID : (total + p->items - 1) / p->items;   // sliced: diff partials of the combine grid
         if ((st = p->blk.alloc((size_t) p->nblk + 1))) break;
-        hipLaunchKernelGGL(pr_blocks_kernel, dim3(grid_for(p->nblk + 1, 256, 1 << 30)), dim3(256), 0, s,
-                           p->rb, p->rows, p->El, p->items, p->nblk, p->blk.p);
+        if (p->ns == 0)
+            hipLaunchKernelGGL(pr_blocks_kernel, dim3(grid_for(p->nblk + 1, 256, 1 << 30)), dim3(256), 0, s,
+                               p->rb, p->rows, p->El, p->items, p->nblk, p->blk.p);
         size_t nb = (size_t) (p->nblk ? p->nblk : 1);
         if ((st = p->part_first.alloc(nb)) || (st = p->part_last.alloc(nb)) || (st = p->diff_part.alloc(2 * nb)) ||
             (st = p->diff.alloc(1)) || (st = p->rk.alloc((size_t) (p->rows ? p->rows : 1) * elem_bytes)) ||
@@ -500,19 +796,63 @@ static void launch_step(gmx_pr* p, hipStream_t s, int grid) {
     const double N = (double) p->V;
     const double base = (1 - p->d) / N;
     S* next_owned = (S*) p->contrib[1 - p->cur].p + p->row_lo;
+    static const int abl = getenv("GMX_PR_ABLATE") ? atoi(getenv("GMX_PR_ABLATE")) : 0;   // development only
+    pr_ev_begin(p, s);
+    if (abl == 1 || abl == 2) {
+        if (abl == 1)
+            hipLaunchKernelGGL((pr_step_kernel<S, THREADS, ITEMS, HOT, true, 1>), dim3(grid), dim3(THREADS), 0, s,
+                               p->blk.p, p->nblk, p->rows, p->rb, p->ridx, p->outdeg.p, (S*) p->rk.p,
+                               (const S*) p->contrib[p->cur].p, next_owned, base, p->d,
+                               p->part_first.p, p->part_last.p, p->diff_part.p);
+        else
+            hipLaunchKernelGGL((pr_step_kernel<S, THREADS, ITEMS, HOT, true, 2>), dim3(grid), dim3(THREADS), 0, s,
+                               p->blk.p, p->nblk, p->rows, p->rb, p->ridx, p->outdeg.p, (S*) p->rk.p,
+                               (const S*) p->contrib[p->cur].p, next_owned, base, p->d,
+                               p->part_first.p, p->part_last.p, p->diff_part.p);
+    } else
     hipLaunchKernelGGL((pr_step_kernel<S, THREADS, ITEMS, HOT, true>), dim3(grid), dim3(THREADS), 0, s,
                        p->blk.p, p->nblk, p->rows, p->rb, p->ridx, p->outdeg.p, (S*) p->rk.p,
                        (const S*) p->contrib[p->cur].p, next_owned, base, p->d,
                        p->part_first.p, p->part_last.p, p->diff_part.p);
+    pr_ev_end(p, s);
     hipLaunchKernelGGL(pr_fixup_kernel<S>, dim3((unsigned) ((p->nblk + 255) / 256)), dim3(256), 0, s,
                        p->blk.p, p->nblk, p->rows, p->rb, p->outdeg.p, (S*) p->rk.p, next_owned, base, p->d,
                        p->part_first.p, p->part_last.p, p->diff_part.p + p->nblk);
 }
 
+template <typename S>
+static void launch_sliced(gmx_pr* p, hipStream_t s) {
+    const double N = (double) p->V;
+    const double base = (1 - p->d) / N;
+    S* next_owned = (S*) p->contrib[1 - p->cur].p + p->row_lo;
+    (void) hipMemsetAsync(p->sl_queue.p, 0, sizeof(unsigned int) * PR_MAX_SLICES, s);
+    int64_t maxblk = 0;
+    for (int q = 0; q < p->ns; q++) maxblk = p->sl.s[q].nblk > maxblk ? p->sl.s[q].nblk : maxblk;
+    int64_t total_blk = 0;
+    for (int q = 0; q < p->ns; q++) total_blk += p->sl.s[q].nblk;
+    int grid = p->persistent_grid * 8;   // 8 workgroups of 256 threads per CU
+    if (grid > total_blk) grid = (int) total_blk;
+    if (grid > 0) {
+        pr_ev_begin(p, s);
+        hipLaunchKernelGGL((pr_sliced_kernel<S, 256, 2048, true>), dim3(grid), dim3(256), 0, s, p->sl, p->rows,
+                           (const S*) p->contrib[p->cur].p);
+        pr_ev_end(p, s);
+        hipLaunchKernelGGL(pr_sliced_fixup_kernel<S>, dim3((unsigned) ((maxblk + 255) / 256), p->ns), dim3(256), 0, s, p->sl, p->rows);
+    }
+    hipLaunchKernelGGL(pr_combine_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, p->sl, p->rows, p->outdeg.p, (S*) p->rk.p,
+                       next_owned, base, p->d, p->diff_part.p);
+}
+
 extern "C" int gmx_pr_step(gmx_pr_t* p, void* stream) {
     GMX_REQUIRE(p, "pr is NULL");
     hipStream_t s = (hipStream_t) stream;
-    if (p->nblk > 0) {
+    if (p->ns > 0) {
+        if (p->rows > 0) {
+            if (p->elem == 4) launch_sliced<float>(p, s);
+            else launch_sliced<double>(p, s);
+            hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) p->diff_part.p, (int64_t) PR_COMBINE_GRID, p->diff.p);
+        }
+    } else if (p->nblk > 0) {
         if (p->hot) {
             int grid = p->persistent_grid < p->nblk ? p->persistent_grid : (int) p->nblk;
             if (p->elem == 4) launch_step<float, 1024, 4096, 28672>(p, s, grid);
@@ -574,12 +914,38 @@ extern "C" int gmx_pr_download(gmx_pr_t* p, void* rank_host) {
     return GMX_OK;
 }
 
+extern "C" int gmx_pr_timing(gmx_pr_t* p, int enable) {
+    GMX_REQUIRE(p, "pr is NULL");
+    p->timing = enable != 0;
+    p->ev_used = 0;
+    return GMX_OK;
+}
+
+extern "C" int gmx_pr_kernel_time(gmx_pr_t* p, int32_t* launches, double* mean_ms) {
+    GMX_REQUIRE(p && launches && mean_ms, "NULL argument");
+    GMX_HIP(hipDeviceSynchronize());
+    double tot = 0.0;
+    for (int i = 0; i < p->ev_used; i++) {
+        float ms = 0;
+        GMX_HIP(hipEventElapsedTime(&ms, p->ev[2 * i], p->ev[2 * i + 1]));
+        tot += ms;
+    }
+    *launches = p->ev_used;
+    *mean_ms = p->ev_used ? tot / p->ev_used : 0.0;
+    return GMX_OK;
+}
+
+extern "C" const char* gmx_pr_kernel_name(gmx_pr_t* p) {
+    if (!p) return "";
+    return p->ns > 0 ? "pr_sliced_kernel" : "pr_step_kernel";
+}
+
 extern "C" int gmx_pr_work(gmx_pr_t* p, int64_t* edges, int64_t* rows, int64_t* algorithmic_bytes) {
     GMX_REQUIRE(p, "pr is NULL");
     if (edges) *edges = p->El;
-    if (rows) *rows = p->rows;
+    if (rows) *rows = p->rows_real;
     // E*(4+s) + V*(8+3s)
-    if (algorithmic_bytes) *algorithmic_bytes = p->El * (4 + p->elem) + p->rows * (8 + 3 * (int64_t) p->elem);
+    if (algorithmic_bytes) *algorithmic_bytes = p->El * (4 + p->elem) + p->rows_real * (8 + 3 * (int64_t) p->elem);
     return GMX_OK;
 }
 

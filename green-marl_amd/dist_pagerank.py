@@ -1,0 +1,104 @@
+"""Multi-GPU PageRank driver: 1-D vertex partition, one process per GPU, RCCL over xGMI.
+
+Mirrors the control flow of the emitted `pagerank` (/root/reference/apps/src/pagerank.gm:9-19):
+    Do { diff = 0; <one sweep over the nodes>; cnt++; } While ((diff > e) && (cnt < max));
+with the sweep split over ranks:
+  * rank k owns an equal-sized, contiguous range of the internally renumbered vertices and a full
+    replica of the contribution vector;
+  * after every sweep the owned ranges are exchanged with ONE in-place all-gather
+    (torch.distributed `all_gather_into_tensor`, backend "nccl" = RCCL): on the fully connected
+    xGMI topology every GPU sends V*s/G bytes to each peer directly, which is the
+    bandwidth-optimal form of the north star's "all-reduce of the rank vector" (owned range
+    filled, rest zero, sum = concatenation);
+  * `diff` is a 1-element fp64 all-reduce(SUM) -- the ATOMIC_ADD<double>(&diff, diff_prv) of the
+    emitted code with ranks in place of threads.
+
+The engine is anything with the gmx.PageRankState stepping interface (step / contrib tensors /
+diff tensor).  The product engine is GmxEngine (HIP kernels through libgmx.so); the CPU tests
+drive the same orchestration over gloo with a test-owned engine.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GmxEngine:
+    """gmx.PageRankState behind the engine interface, tensors wrapping the library's HBM buffers."""
+
+    def __init__(self, gmx, graph, elem_bytes, rank, nranks, options):
+        self.gmx = gmx
+        self.state = gmx.PageRankState(graph, elem_bytes, rank, nranks, options)
+        self._cache = {}
+
+    def _wrap(self, dev_array):
+        cai = dev_array.__cuda_array_interface__
+        key = (cai["data"][0], cai["shape"][0], cai["typestr"])
+        t = self._cache.get(key)
+        if t is None:
+            t = torch.as_tensor(dev_array, device="cuda")
+            self._cache[key] = t
+        return t
+
+    def reset(self, d):
+        self.state.reset(d)
+
+    def step(self):
+        self.state.step(None)   # default stream == torch's current stream: ordered with the collectives
+
+    def contrib_slice(self):
+        return self._wrap(self.state.contrib_slice())
+
+    def contrib_full(self):
+        return self._wrap(self.state.contrib_full())
+
+    def diff_tensor(self):
+        return self._wrap(self.state.diff_dev())
+
+    def download(self, out=None):
+        return self.state.download(out)
+
+
+class DistPageRank:
+    def __init__(self, engine, group=None):
+        self.engine = engine
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.cnt = 0
+
+    def _exchange(self):
+        if self.world == 1:
+            return
+        full = self.engine.contrib_full()
+        mine = self.engine.contrib_slice()
+        backend = dist.get_backend(self.group)
+        if backend == "gloo":
+            parts = list(full.chunk(self.world))
+            dist.all_gather(parts, mine.clone(), group=self.group)
+        else:
+            dist.all_gather_into_tensor(full, mine, group=self.group)
+
+    def reset(self, d=0.85):
+        self.engine.reset(d)
+        self.cnt = 0
+        self._exchange()
+
+    def step(self):
+        """One PageRank iteration of the whole job (local sweep + exchange); asynchronous on GPU."""
+        self.engine.step()
+        self._exchange()
+        self.cnt += 1
+
+    def diff(self):
+        t = self.engine.diff_tensor()
+        if self.world > 1:
+            t = t.clone()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return float(t.item())
+
+    def run(self, e=0.001, d=0.85, max_iter=100):
+        self.reset(d)
+        while True:
+            self.step()
+            diff = self.diff()
+            if not (diff > e and self.cnt < max_iter):
+                break
+        return self.cnt, diff

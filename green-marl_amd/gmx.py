@@ -16,6 +16,7 @@ GMX_GRAPH_SORT_ROWS = 0x1
 GMX_GRAPH_NO_REVERSE = 0x2
 GMX_PR_RELABEL = 0x1
 GMX_PR_HOT_LDS = 0x2
+GMX_PR_SLICED = 0x4
 INT_MAX = 2147483647
 
 
@@ -45,6 +46,7 @@ EXPORTS = [
     "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_triangle_counting",
     "gmx_pr_create", "gmx_pr_free", "gmx_pr_reset", "gmx_pr_step", "gmx_pr_contrib_slice",
     "gmx_pr_contrib_full", "gmx_pr_diff_ptr", "gmx_pr_diff", "gmx_pr_download", "gmx_pr_work",
+    "gmx_pr_timing", "gmx_pr_kernel_time", "gmx_pr_kernel_name",
 ]
 
 _LIB = None
@@ -86,6 +88,10 @@ def lib():
         L.gmx_pr_diff.argtypes = [vp, vp, C.POINTER(C.c_double)]
         L.gmx_pr_download.argtypes = [vp, vp]
         L.gmx_pr_work.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+        L.gmx_pr_timing.argtypes = [vp, C.c_int]
+        L.gmx_pr_kernel_time.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_double)]
+        L.gmx_pr_kernel_name.argtypes = [vp]
+        L.gmx_pr_kernel_name.restype = C.c_char_p
         _LIB = L
     return _LIB
 
@@ -276,6 +282,18 @@ class PageRankState:
             out = np.zeros(max(V, 1), dt)[:V].copy()
         _ck(lib().gmx_pr_download(self._h, out.ctypes.data))
         return out
+
+    def timing(self, enable=True):
+        _ck(lib().gmx_pr_timing(self._h, int(enable)))
+
+    def kernel_time(self):
+        """(launches, mean_ms) of the dominant kernel since timing(True), hipEvents on its stream."""
+        n, ms = C.c_int32(0), C.c_double(0)
+        _ck(lib().gmx_pr_kernel_time(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def kernel_name(self):
+        return lib().gmx_pr_kernel_name(self._h).decode()
 
     def work(self):
         e, r, b = C.c_int64(0), C.c_int64(0), C.c_int64(0)

@@ -1,0 +1,116 @@
+"""CPU: the N > 1 orchestration (green-marl_amd/dist_pagerank.py) over gloo, world_size 2 and 3.
+The local sweep is a test-owned numpy engine (the oracle's arithmetic on a 1-D vertex slice);
+what is under test is the exchange / diff / termination logic the GPU ranks run unchanged."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import pyoracle as po
+
+
+class NumpyEngine:
+    """Owns rows [lo, hi) of an equal 1-D split; same stepping interface as dist_pagerank.GmxEngine."""
+
+    def __init__(self, g, rank, world):
+        self.g, self.rank, self.world = g, rank, world
+        self.slice = (g.N + world - 1) // world
+        self.lo = rank * self.slice
+        self.hi = min(g.N, self.lo + self.slice)
+        self.outdeg = np.diff(g.begin).astype(np.float64)
+        self.dst = np.repeat(np.arange(g.N), np.diff(g.r_begin))
+        self.sel = (self.dst >= self.lo) & (self.dst < self.hi)
+        self.contrib = [torch.zeros(self.slice * world, dtype=torch.float64) for _ in range(2)]
+        self.cur = 0
+        self.rank_v = np.zeros(max(self.hi - self.lo, 0))
+        self._diff = torch.zeros(1, dtype=torch.float64)
+
+    def _contrib_of(self, r):
+        od = self.outdeg[self.lo:self.hi]
+        return np.where(od > 0, r / np.maximum(od, 1), 0.0)
+
+    def reset(self, d):
+        self.d = d
+        self.cur = 0
+        self.rank_v[:] = 1.0 / self.g.N
+        self.contrib[0].zero_()
+        self.contrib[0][self.lo:self.hi] = torch.from_numpy(self._contrib_of(self.rank_v))
+
+    def step(self):
+        c = self.contrib[self.cur].numpy()
+        sums = np.bincount(self.dst[self.sel] - self.lo, weights=c[self.g.r_node_idx[self.sel]],
+                           minlength=self.hi - self.lo)
+        val = (1 - self.d) / self.g.N + self.d * sums
+        self._diff[0] = np.abs(val - self.rank_v).sum()
+        self.rank_v = val
+        nxt = self.contrib[1 - self.cur]
+        nxt[self.lo:self.hi] = torch.from_numpy(self._contrib_of(val))
+        self.cur = 1 - self.cur
+
+    def contrib_slice(self):
+        return self.contrib[self.cur][self.lo:self.lo + self.slice]
+
+    def contrib_full(self):
+        return self.contrib[self.cur]
+
+    def diff_tensor(self):
+        return self._diff
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, scale, out_dir):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.join(here, "..", "green-marl_amd"), os.path.join(here, "..", "oracle")):
+        sys.path.insert(0, os.path.abspath(p))
+    from dist_pagerank import DistPageRank
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = po.rmat_graph(scale, permute=True)
+    eng = NumpyEngine(g, rank, world)
+    pr = DistPageRank(eng)
+    cnt, diff = pr.run(0.001, 0.85, 100)
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), eng.rank_v)
+    np.save(os.path.join(out_dir, "meta%d.npy" % rank), np.array([cnt, diff, eng.lo, eng.hi]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_dist_pagerank_gloo(tmp_path, world):
+    scale = 11
+    mp.spawn(_worker, args=(world, _free_port(), scale, str(tmp_path)), nprocs=world, join=True)
+    g = po.rmat_graph(scale, permute=True)
+    want, it, want_diff = po.pagerank(g, 0.001, 0.85, 100, nthreads=1)
+    got = np.zeros(g.N)
+    for r in range(world):
+        cnt, diff, lo, hi = np.load(tmp_path / ("meta%d.npy" % r))
+        assert int(cnt) == it
+        assert abs(diff - want_diff) < 1e-12
+        got[int(lo):int(hi)] = np.load(tmp_path / ("rank%d.npy" % r))
+    assert np.max(np.abs(got - want) / want) < 1e-12
+
+
+def test_single_process_world1():
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "green-marl_amd"))
+    from dist_pagerank import DistPageRank
+    g = po.rmat_graph(10)
+    pr = DistPageRank(NumpyEngine(g, 0, 1))
+    cnt, _ = pr.run(0.001, 0.85, 100)
+    want, it, _ = po.pagerank(g, 0.001, 0.85, 100, nthreads=1)
+    assert cnt == it
+    assert np.max(np.abs(pr.engine.rank_v - want) / want) < 1e-12

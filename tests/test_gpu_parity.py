@@ -86,7 +86,7 @@ def test_pagerank_golden_f32(gmx, golden):
         g.free()
 
 
-@pytest.mark.parametrize("options", [0, 1, 3])
+@pytest.mark.parametrize("options", [0, 1, 3, 5])
 @pytest.mark.parametrize("elem", [4, 8])
 def test_pagerank_stepping_variants(gmx, golden, options, elem):
     """Every kernel variant (identity numbering / degree-sorted / LDS hot tile) for 20 fixed iterations."""
@@ -192,4 +192,56 @@ def test_from_edges_matches_oracle(gmx):
     begin, node_idx, rb, rn = g.download()
     assert np.array_equal(begin, og.begin) and np.array_equal(node_idx, og.node_idx)
     assert np.array_equal(rb, og.r_begin) and np.array_equal(rn, og.r_node_idx)
+    g.free()
+
+
+@pytest.mark.parametrize("nranks,options", [(2, 1), (4, 1), (3, 0), (2, 5)])
+def test_pagerank_partitioned_ranks_in_one_process(gmx, nranks, options):
+    """The C library's 1-D partition for N ranks, exercised on one GPU: every rank's state lives in
+    this process and the all-gather is done with plain device copies (torch), then compared with
+    the oracle.  (The collective itself is covered by tests/test_dist_gloo.py on CPU.)"""
+    import torch
+    og = po.rmat_graph(15, permute=True)
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    want, it, _ = po.pagerank(og, 1e-300, 0.85, 12)
+    states = [gmx.PageRankState(g, 8, r, nranks, options) for r in range(nranks)]
+
+    def exchange():
+        fulls = [torch.as_tensor(s.contrib_full(), device="cuda") for s in states]
+        slices = [torch.as_tensor(s.contrib_slice(), device="cuda") for s in states]
+        n = slices[0].numel()
+        for dst in fulls:
+            for r, src in enumerate(slices):
+                dst[r * n:(r + 1) * n].copy_(src)
+        torch.cuda.synchronize()
+
+    for s in states:
+        s.reset(0.85)
+    exchange()
+    for _ in range(12):
+        for s in states:
+            s.step()
+        exchange()
+    out = np.zeros(og.N)
+    for s in states:
+        s.download(out)
+    assert rel_err(out, want) < PR_RTOL_F64
+    assert sum(s.work()["edges"] for s in states) == og.M
+    for s in states:
+        s.free()
+    g.free()
+
+
+def test_dist_engine_world1_and_kernel_timing(gmx):
+    from dist_pagerank import DistPageRank, GmxEngine
+    og = po.rmat_graph(14, permute=True)
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    eng = GmxEngine(gmx, g, 4, 0, 1, gmx.GMX_PR_RELABEL)
+    pr = DistPageRank(eng)
+    eng.state.timing(True)
+    cnt, diff = pr.run(0.001, 0.85, 100)
+    n, ms = eng.state.kernel_time()
+    want, it, _ = po.pagerank(og, 0.001, 0.85, 100)
+    assert cnt == it and n == cnt and ms > 0
+    assert rel_err(eng.download(), want) < PR_RTOL_F32
     g.free()
