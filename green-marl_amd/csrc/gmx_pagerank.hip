@@ -493,17 +493,21 @@ __device__ __forceinline__ void pr_fixup_one(const pr_blk* __restrict__ blk, int
 }
 
 template <typename S>
-__global__ void pr_fixup_kernel(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
-                                const int32_t* __restrict__ rb, const int32_t* __restrict__ outdeg,
-                                S* __restrict__ rk, S* __restrict__ contrib_next_owned, double base, double d,
-                                double* __restrict__ part_first, double* __restrict__ part_last,
-                                double* __restrict__ diff_fix) {
+__global__ void __launch_bounds__(256)
+pr_fixup_kernel(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
+                const int32_t* __restrict__ rb, const int32_t* __restrict__ outdeg,
+                S* __restrict__ rk, S* __restrict__ contrib_next_owned, double base, double d,
+                double* __restrict__ part_first, double* __restrict__ part_last,
+                const double* __restrict__ diff_main, double* __restrict__ diff_out) {
+    __shared__ double s_red[256 / 64];
     int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nblk) return;
     double diff_acc = 0.0;
-    out_final<S> out{rk, outdeg, contrib_next_owned, base, d, part_first, part_last};
-    pr_fixup_one<S>(blk, nblk, rows, rb, k, out, diff_acc);
-    diff_fix[k] = diff_acc;
+    if (k < nblk) {
+        out_final<S> out{rk, outdeg, contrib_next_owned, base, d, part_first, part_last};
+        pr_fixup_one<S>(blk, nblk, rows, rb, k, out, diff_acc);
+        diff_acc += diff_main[k];   // fold in the main kernel's workgroup partial (fixed order)
+    }
+    pr_block_diff<256>(diff_acc, s_red, diff_out + blockIdx.x);
 }
 
 template <typename S>
@@ -817,7 +821,7 @@ static void launch_step(gmx_pr* p, hipStream_t s, int grid) {
     pr_ev_end(p, s);
     hipLaunchKernelGGL(pr_fixup_kernel<S>, dim3((unsigned) ((p->nblk + 255) / 256)), dim3(256), 0, s,
                        p->blk.p, p->nblk, p->rows, p->rb, p->outdeg.p, (S*) p->rk.p, next_owned, base, p->d,
-                       p->part_first.p, p->part_last.p, p->diff_part.p + p->nblk);
+                       p->part_first.p, p->part_last.p, (const double*) p->diff_part.p, p->diff_part.p + p->nblk);
 }
 
 template <typename S>
@@ -862,7 +866,7 @@ extern "C" int gmx_pr_step(gmx_pr_t* p, void* stream) {
             if (p->elem == 4) launch_step<float, 256, 2048, 0>(p, s, (int) p->nblk);
             else launch_step<double, 256, 2048, 0>(p, s, (int) p->nblk);
         }
-        hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) p->diff_part.p, 2 * p->nblk, p->diff.p);
+        hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) (p->diff_part.p + p->nblk), (p->nblk + 255) / 256, p->diff.p);
     }
     GMX_HIP(hipGetLastError());
     p->cur = 1 - p->cur;

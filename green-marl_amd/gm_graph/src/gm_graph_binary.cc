@@ -1,0 +1,98 @@
+// gm_graph_binary.cc -- the custom binary graph format.
+// Format (all big-endian; /root/reference/apps/output_cpp/gm_graph/src/gm_graph_binary_loader.cc:19-26):
+//   magic 0x03939999 | sizeof(node_t) | sizeof(edge_t) | N | M | begin[N+1] | node_idx[M]
+// A byte-flipped legacy variant (magic readable without swapping) is accepted too (:68-87).
+// Like the reference (:191-197) a loaded graph is semi-sorted and gets its reverse edges.
+// The reference reads element by element; this reader pulls each array with one fread and swaps in parallel.
+#include <arpa/inet.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gm_graph.h"
+
+static bool read_u32_array(FILE* f, int32_t* dst, size_t n, bool swap) {
+    if (n && fread(dst, 4, n, f) != n) return false;
+    if (swap) {
+#pragma omp parallel for
+        for (size_t i = 0; i < n; i++) dst[i] = (int32_t) ntohl((uint32_t) dst[i]);
+    }
+    return true;
+}
+
+bool gm_graph::load_binary(char* filename) {
+    clear_graph();
+    FILE* f = fopen(filename, "rb");
+    if (f == NULL) {
+        fprintf(stderr, "cannot open %s for reading\n", filename);
+        return false;
+    }
+    uint32_t hdr[3];
+    bool ok = fread(hdr, 4, 3, f) == 3;
+    bool swap = true;
+    if (ok) {
+        if (ntohl(hdr[0]) == MAGIC_WORD_BIN) swap = true;
+        else if (hdr[0] == MAGIC_WORD_BIN) swap = false;
+        else {
+            fprintf(stderr, "wrong file format, KEY mismatch: %08x, expected:%08x\n", ntohl(hdr[0]), MAGIC_WORD_BIN);
+            ok = false;
+        }
+    } else fprintf(stderr, "wrong file format\n");
+    uint32_t nsz = 0, esz = 0;
+    if (ok) {
+        nsz = swap ? ntohl(hdr[1]) : hdr[1];
+        esz = swap ? ntohl(hdr[2]) : hdr[2];
+        if (nsz != sizeof(node_t) || esz != sizeof(edge_t)) {
+            fprintf(stderr, "node_t/edge_t size mismatch: file has %u/%u bytes, library expects %zu/%zu; please re-generate the graph\n",
+                    nsz, esz, sizeof(node_t), sizeof(edge_t));
+            ok = false;
+        }
+    }
+    int32_t nm[2] = {0, 0};
+    if (ok) ok = read_u32_array(f, nm, 2, swap);
+    if (ok && (nm[0] < 0 || nm[1] < 0)) ok = false;
+    if (ok) {
+        printf("N = %ld, M = %ld\n", (long) nm[0], (long) nm[1]);
+        prepare_external_creation(nm[0], nm[1]);
+        ok = read_u32_array(f, begin, (size_t) nm[0] + 1, swap) && read_u32_array(f, node_idx, (size_t) nm[1], swap);
+        if (!ok) fprintf(stderr, "Error reading the CSR arrays\n");
+        else if (begin[0] != 0 || begin[nm[0]] != nm[1]) {
+            fprintf(stderr, "corrupt file: begin[] does not cover the edge array\n");
+            ok = false;
+        }
+    }
+    fclose(f);
+    if (!ok) {
+        clear_graph();
+        return false;
+    }
+    do_semi_sort();
+    make_reverse_edges();
+    return true;
+}
+
+bool gm_graph::store_binary(char* filename) {
+    if (!_frozen) freeze();
+    FILE* f = fopen(filename, "wb");
+    if (f == NULL) {
+        fprintf(stderr, "cannot open %s for writing\n", filename);
+        return false;
+    }
+    const size_t N = (size_t) _numNodes, M = (size_t) _numEdges;
+    uint32_t hdr[5] = {htonl(MAGIC_WORD_BIN), htonl((uint32_t) sizeof(node_t)), htonl((uint32_t) sizeof(edge_t)),
+                       htonl((uint32_t) _numNodes), htonl((uint32_t) _numEdges)};
+    bool ok = fwrite(hdr, 4, 5, f) == 5;
+    const size_t chunk = 1 << 20;
+    uint32_t* buf = new uint32_t[chunk];
+    for (int pass = 0; pass < 2 && ok; pass++) {
+        const int32_t* src = pass == 0 ? begin : node_idx;
+        const size_t n = pass == 0 ? N + 1 : M;
+        for (size_t off = 0; off < n && ok; off += chunk) {
+            const size_t c = n - off < chunk ? n - off : chunk;
+            for (size_t i = 0; i < c; i++) buf[i] = htonl((uint32_t) src[off + i]);
+            ok = fwrite(buf, 4, c, f) == c;
+        }
+    }
+    delete[] buf;
+    fclose(f);
+    return ok;
+}

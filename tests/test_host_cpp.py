@@ -1,0 +1,117 @@
+"""The C++ host side: gm_graph API (clean room, reference-compatible), generated-style entry
+points and benchmark drivers.  CPU tests need no GPU (they never touch the device mirror);
+the driver runs are GPU tests."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT
+
+PKG = os.path.join(ROOT, "green-marl_amd")
+REF_APPS = "/root/reference/apps/output_cpp/src"
+CXX_FLAGS = ["-O2", "-fopenmp", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "gm_graph", "inc"),
+             "-I" + os.path.join(PKG, "generated"), "-I" + os.path.join(PKG, "apps")]
+LINK = [os.path.join(PKG, "libgmgraph.a"), "-L" + PKG, "-lgmx", "-Wl,-rpath," + PKG, "-L/opt/rocm/lib",
+        "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64"]
+
+
+@pytest.fixture(scope="module")
+def host_built():
+    subprocess.check_call(["make", "-C", PKG, "-j4", "lib", "host"], stdout=subprocess.DEVNULL)
+    return PKG
+
+
+def parse_dump(path):
+    out = {}
+    for line in open(path):
+        k, *v = line.split()
+        out[k] = np.array([int(x) for x in v], np.int64)
+    return out
+
+
+def test_gm_graph_api(host_built, golden, tmp_path):
+    exe = str(tmp_path / "gm_graph_check")
+    subprocess.check_call(["g++"] + CXX_FLAGS + [os.path.join(ROOT, "tests", "cpp", "gm_graph_check.cc"), "-o", exe] + LINK)
+    src = os.path.join(GOLD, golden["manifest"]["bin"]["file"])
+    out_bin, dump = str(tmp_path / "o.bin"), str(tmp_path / "d.txt")
+    r = subprocess.run([exe, src, out_bin, dump], stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout)
+    assert "N = 256, M = 4096" in r.stdout                       # gm_graph_binary_loader.cc:136
+    assert open(out_bin, "rb").read() == open(src, "rb").read()   # byte-identical with the reference's writer
+    d = parse_dump(dump)
+    c = golden["cases"]["rmat8_noperm"]
+    for k in ("begin", "node_idx", "r_begin", "r_node_idx"):
+        assert np.array_equal(d[k], c[k]), k
+    # hand graph: rows sorted, reverse rows sorted by source
+    assert d["h_begin"].tolist() == [0, 4, 4, 6, 7, 7, 8]
+    assert d["h_node_idx"].tolist() == [1, 1, 3, 5, 0, 1, 3, 4]
+    assert d["h_r_begin"].tolist() == [0, 1, 4, 4, 6, 7, 8]
+    assert d["h_r_node_idx"].tolist() == [2, 0, 0, 2, 0, 3, 5, 0]
+    assert d["h_node_idx_src"].tolist() == [0, 0, 0, 0, 2, 2, 3, 5]
+    assert d["h_r_node_idx_src"].tolist() == [0, 1, 1, 1, 3, 3, 4, 5]
+    # gm_rand32 sequence = the reference's update rule (gm_rand.cc:19-24) from its default seed
+    x = np.int32(np.uint32(2463534242))
+    want = []
+    for _ in range(3):
+        x = np.int32(np.uint32(x) ^ np.uint32((int(np.uint32(x)) << 13) & 0xffffffff))
+        x = np.int32(x >> 17)
+        x = np.int32(np.uint32(x) ^ np.uint32((int(np.uint32(x)) << 5) & 0xffffffff))
+        want.append(int(x))
+    assert d["rand32"].tolist() == want
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_APPS), reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("app", ["pagerank", "hop_dist", "triangle_counting"])
+def test_reference_drivers_compile_unchanged(host_built, tmp_path, app):
+    """Drop-in check: the REFERENCE's own driver sources (common_main.h + <app>_main.cc), untouched and
+    compiled where they lie, build and link against this repo's gm.h / generated headers / libraries."""
+    exe = str(tmp_path / app)
+    flags = [f for f in CXX_FLAGS if "apps" not in f]   # the reference's common_main.h, not ours
+    cmd = ["g++"] + flags + ["-I" + REF_APPS, "-w", os.path.join(REF_APPS, app + "_main.cc"), "-o", exe] + LINK
+    subprocess.check_call(cmd)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, text=True)       # no args: usage line, exit(EXIT_FAILURE)
+    assert r.returncode == 1 and "<graph_name> <num_threads> <nfspath>" in r.stdout
+
+
+def run_app(app, *args):
+    r = subprocess.run([os.path.join(PKG, "bin", app)] + list(args), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "XXXXXXXXXX GM DONE XXXXXXXXXXXXXX" in r.stdout
+    assert re.search(r"running time=\d+\.\d+", r.stdout)
+    return r.stdout
+
+
+@pytest.mark.gpu
+def test_drivers_on_golden_bin(host_built, golden):
+    src = os.path.join(GOLD, golden["manifest"]["bin"]["file"])
+    c = golden["cases"]["rmat8_noperm"]
+    m = golden["manifest"]["rmat"]["rmat8_noperm"]
+    out = run_app("pagerank", src, "4", "/dev/null")
+    got = [float(x) for x in re.findall(r"rank\[\d\] = ([0-9.]+)", out)]
+    assert got == [float("%0.9f" % x) for x in c["rank"][:4]]
+    out = run_app("pagerank", src, "4", "/dev/null", "100", "0.001", "0.85", "f32")
+    got32 = [float(x) for x in re.findall(r"rank\[\d\] = ([0-9.]+)", out)]
+    assert np.allclose(got32, c["rank"][:4], rtol=1e-5, atol=1e-9)
+    out = run_app("hop_dist", src, "4", "/dev/null")
+    assert [int(x) for x in re.findall(r"dist\[\d\] = (\d+)", out)] == c["dist"][:10].tolist()
+    out = run_app("triangle_counting", src, "4", "/dev/null")
+    assert int(re.search(r"number of triangles: (\d+)", out).group(1)) == m["tc_directed"]
+
+
+@pytest.mark.gpu
+def test_driver_rmat_input(host_built, golden):
+    m = golden["manifest"]["rmat"]["rmat14_noperm"]
+    out = run_app("hop_dist", "RMAT:14:0", "4", "/dev/null")
+    assert "N = 16384, M = 262144" in out
+    out = run_app("pagerank", "RMAT:14:0", "4", "/dev/null")
+    got = [float(x) for x in re.findall(r"rank\[\d\] = ([0-9.]+)", out)]
+    assert got == [float("%0.9f" % x) for x in m["rank_head"]]
+
+
+@pytest.mark.gpu
+def test_gmx_bench_tool(host_built):
+    r = subprocess.run([os.path.join(PKG, "bin", "gmx_bench")], stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and "gfx950" in r.stdout
