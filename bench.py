@@ -80,7 +80,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     elem = 4 if args.dtype == "f32" else 8
-    options = gmx.GMX_PR_RELABEL if args.options < 0 else args.options
+    options = gmx.default_pr_options(1 << args.scale, world) if args.options < 0 else args.options
     N, M = 1 << args.scale, 16 << args.scale
 
     cpu = None

@@ -6,10 +6,11 @@
 // The result (BFS depth from root) is unique, so the device version is free to choose the
 // traversal: direction-optimising as the reference's own runtime BFS does
 // (apps/output_cpp/gm_graph/inc/gm_bfs_template.h:352-421):
-//   * top-down:  frontier queue; a wave takes 64 frontier vertices, expands rows >= 64 edges
-//                cooperatively (coalesced node_idx reads) and the rest lane-serially;
-//                first-writer-wins via atomicMin on dist (the emitted `min=`), next queue
-//                built with __ballot-aggregated appends;
+//   * top-down:  frontier queue; the out-degrees of the frontier are prefix-summed and the
+//                (vertex, edge) sequence is cut by merge-path into equal pieces, so a hub row is
+//                spread over the whole chip and consecutive lanes read consecutive node_idx
+//                entries; first-writer-wins via atomicMin on dist (the emitted `min=`), next
+//                queue built with __ballot-aggregated appends;
 //   * bottom-up: when the frontier exceeds 5 % of V (RRD_THRESHOLD, gm_bfs_template.h:359),
 //                every unvisited vertex scans its in-row for a parent whose bit is set in the
 //                frontier bitmap (V/8 bytes: fits L2) and stops at the first hit.
@@ -18,6 +19,7 @@
 
 #include <limits.h>
 #include <string.h>
+#include <rocprim/rocprim.hpp>
 
 #define BFS_THREADS 256
 
@@ -48,43 +50,65 @@ __device__ __forceinline__ void bfs_visit(int32_t s, int32_t next_level, int32_t
     }
 }
 
+#define BFS_ITEMS 2048   // merge-path items (frontier vertices + their out-edges) per workgroup
+
+__global__ void bfs_degree_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ q, int64_t n,
+                                  int32_t* __restrict__ deg) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        int32_t v = q[i];
+        deg[i] = begin[v + 1] - begin[v];
+    }
+}
+
+// off[0..n] = exclusive prefix sums of the frontier degrees (off[n] = frontier edges).
+// Block k handles path items [k*BFS_ITEMS, (k+1)*BFS_ITEMS) of the merged (vertex ends, edges) sequence.
 __global__ void __launch_bounds__(BFS_THREADS)
 bfs_topdown_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx,
-                   const int32_t* __restrict__ cur_q, int64_t cur_count, int32_t level,
-                   int32_t* __restrict__ dist, int32_t* __restrict__ next_q, bfs_counters* __restrict__ ctr) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t) gridDim.x * blockDim.x) >> 6;
+                   const int32_t* __restrict__ cur_q, int64_t n, const int64_t* __restrict__ off, int64_t m,
+                   int32_t level, int32_t* __restrict__ dist, int32_t* __restrict__ next_q,
+                   bfs_counters* __restrict__ ctr) {
+    __shared__ int64_t s_off[BFS_ITEMS + 2];
+    __shared__ int32_t s_row[BFS_ITEMS + 2];
+    __shared__ int64_t s_split[2][2];
+    const int tid = threadIdx.x;
+    if (tid < 2) {   // merge-path split of diagonals k*ITEMS and (k+1)*ITEMS
+        int64_t dk = ((int64_t) blockIdx.x + tid) * BFS_ITEMS;
+        if (dk > n + m) dk = n + m;
+        int64_t lo = dk > m ? dk - m : 0, hi = dk < n ? dk : n;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (off[mid + 1] <= dk - mid - 1) lo = mid + 1; else hi = mid;
+        }
+        s_split[tid][0] = lo;
+        s_split[tid][1] = dk - lo;
+    }
+    __syncthreads();
+    const int64_t v0 = s_split[0][0], e0 = s_split[0][1], v1 = s_split[1][0], e1 = s_split[1][1];
+    const int nv = (int) (v1 - v0) + 1;   // frontier slots touched (the last one may be partial / == n)
+    for (int i = tid; i < nv; i += BFS_THREADS) {
+        int64_t vi = v0 + i;
+        s_off[i] = vi <= n ? off[vi < n ? vi : n] : m;
+        s_row[i] = vi < n ? begin[cur_q[vi]] : 0;
+    }
+    if (tid == 0) s_off[nv] = m + 1;   // sentinel
+    __syncthreads();
     unsigned long long inspected = 0;
-    for (int64_t base = wave * 64; base < cur_count; base += nwaves * 64) {
-        int64_t qi = base + lane;
-        int32_t rb = 0, re = 0;
-        if (qi < cur_count) {
-            int32_t n = cur_q[qi];
-            rb = begin[n];
-            re = begin[n + 1];
+    for (int64_t x = e0 + tid; x < e1; x += BFS_THREADS) {
+        // frontier slot of edge x: last i with s_off[i] <= x
+        int lo = 0, hi = nv - 1;
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (s_off[mid] <= x) lo = mid; else hi = mid - 1;
         }
-        // rows with >= 64 edges: the whole wave walks them, coalesced
-        unsigned long long big = __ballot(re - rb >= 64);
-        while (big) {
-            int src_lane = __ffsll((long long) big) - 1;
-            big &= big - 1;
-            int32_t b = __shfl(rb, src_lane, 64), e = __shfl(re, src_lane, 64);
-            for (int32_t i = b + lane; i < e; i += 64) {
-                inspected++;
-                bfs_visit(node_idx[i], level + 1, dist, next_q, ctr);
-            }
-            if (lane == src_lane) re = rb;  // done
-        }
-        // remaining short rows: lane-serial (__ballot only counts the lanes still active)
-        for (int32_t i = rb; i < re; i++) {
-            inspected++;
-            bfs_visit(node_idx[i], level + 1, dist, next_q, ctr);
-        }
+        int32_t s = node_idx[(int64_t) s_row[lo] + (x - s_off[lo])];
+        inspected++;
+        bfs_visit(s, level + 1, dist, next_q, ctr);
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) inspected += __shfl_down(inspected, off, 64);
-    if (lane == 0 && inspected) atomicAdd(&ctr->edges, inspected);
+    for (int o = 32; o > 0; o >>= 1) inspected += __shfl_down(inspected, o, 64);
+    if ((tid & 63) == 0 && inspected) atomicAdd(&ctr->edges, inspected);
 }
 
 // bitmap of the vertices in cur_q
@@ -167,12 +191,20 @@ extern "C" int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host,
     dbuf<uint32_t> bm0, bm1;
     dbuf<bfs_counters> ctr;
     dbuf<unsigned long long> qcount;
+    dbuf<int32_t> deg;
+    dbuf<int64_t> off;
+    dbuf<char> scan_tmp;
+    size_t scan_bytes = 0;
     const size_t bmw = (size_t) ((V + 31) / 32);
     GMX_CHECK(dist.alloc((size_t) V));
     GMX_CHECK(q0.alloc((size_t) V));
     GMX_CHECK(q1.alloc((size_t) V));
     GMX_CHECK(ctr.alloc(1));
     GMX_CHECK(qcount.alloc(1));
+    GMX_CHECK(deg.alloc((size_t) V));
+    GMX_CHECK(off.alloc((size_t) V + 2));
+    GMX_HIP(rocprim::inclusive_scan(nullptr, scan_bytes, deg.p, off.p + 1, (size_t) V, rocprim::plus<int64_t>(), 0));
+    GMX_CHECK(scan_tmp.alloc(scan_bytes));
     const bool can_bottom_up = g->has_reverse;
     if (can_bottom_up) {
         GMX_CHECK(bm0.alloc(bmw));
@@ -218,10 +250,20 @@ extern "C" int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host,
                 hipLaunchKernelGGL(bfs_bitmap_to_queue_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, bm0.p, V, cur_q, qcount.p);
                 frontier_is_bitmap = false;
             }
-            int64_t waves = (cur_count + 63) / 64;
-            int blocks = grid_for(waves * 64);
-            hipLaunchKernelGGL(bfs_topdown_kernel, dim3(blocks), dim3(BFS_THREADS), 0, 0,
-                               g->begin.p, g->node_idx.p, cur_q, cur_count, level, dist.p, next_q, ctr.p);
+            // degrees -> exclusive scan -> merge-path expansion
+            hipLaunchKernelGGL(bfs_degree_kernel, dim3(grid_for(cur_count)), dim3(BFS_THREADS), 0, 0, g->begin.p, cur_q, cur_count, deg.p);
+            GMX_HIP(hipMemsetAsync(off.p + cur_count, 0, sizeof(int64_t), 0));
+            {
+                size_t tb = scan_bytes;
+                GMX_HIP(rocprim::inclusive_scan(scan_tmp.p, tb, deg.p, off.p + 1, (size_t) cur_count, rocprim::plus<int64_t>(), 0));
+                GMX_HIP(hipMemsetAsync(off.p, 0, sizeof(int64_t), 0));
+            }
+            int64_t m_f = 0;
+            GMX_HIP(hipMemcpy(&m_f, off.p + cur_count, sizeof(int64_t), hipMemcpyDeviceToHost));
+            int64_t nb = (cur_count + m_f + BFS_ITEMS - 1) / BFS_ITEMS;
+            if (nb > 0)
+                hipLaunchKernelGGL(bfs_topdown_kernel, dim3((unsigned) nb), dim3(BFS_THREADS), 0, 0,
+                                   g->begin.p, g->node_idx.p, cur_q, cur_count, off.p, m_f, level, dist.p, next_q, ctr.p);
             int32_t* t = cur_q; cur_q = next_q; next_q = t;
         }
         GMX_HIP(hipGetLastError());

@@ -31,6 +31,9 @@ struct pr_blk { int32_t r, e; };  // merge-path start of a workgroup: local row 
 
 #define PR_MAX_SLICES 8
 #define PR_COMBINE_GRID 4096
+#define PR_QUEUE_STRIDE 64       // work-queue counters live 256 bytes apart (one atomic unit each)
+#define PR_QUEUE_CHUNK 4         // merge-path blocks (2048 items) claimed per dequeue by a workgroup
+#define PRW_QUEUE_CHUNK 16       // merge-path blocks (512 items) claimed per dequeue by a wave
 #define PR_RUN_SHIFT 11         // sliced numbering: a slice owns runs of 2^11 consecutive ids (all L2 channels)
 
 // Per-slice device arrays of the XCD-sliced variant: slice s holds the in-edges whose SOURCE
@@ -75,6 +78,9 @@ struct gmx_pr {
     int64_t nblk = 0;
     int items = 0, threads = 0;
     bool hot = false;
+    bool wave = false;   // wave-worker kernels
+    int n_main = 0;      // per-wave |val-rank| partials of the last wave-kernel launch
+    int64_t n_fix_blocks = 0;
     int persistent_grid = 0;
     dbuf<pr_blk> blk;     // [nblk+1]
     dbuf<double> part_first, part_last;   // [nblk] partial row sums leaving a workgroup
@@ -257,14 +263,15 @@ template <typename S>
 __device__ __forceinline__ void pr_finalize(int64_t r, double sum, double base, double d,
                                             S* __restrict__ rk, const int32_t* __restrict__ outdeg,
                                             S* __restrict__ contrib_next_owned, double& diff_acc) {
-    const int32_t od = outdeg[r];
+    // streamed once per iteration: non-temporal, so the caches keep the gathered contrib lines
+    const int32_t od = __builtin_nontemporal_load(outdeg + r);
     if (od < 0) return;   // padding row of the sliced numbering: no vertex lives here
     double val = base + d * sum;
-    double old = (double) rk[r];
+    double old = (double) __builtin_nontemporal_load(rk + r);
     S vs = (S) val;
     diff_acc += fabs((double) vs - old);
-    rk[r] = vs;
-    contrib_next_owned[r] = od > 0 ? (S) ((double) vs / (double) od) : (S) 0;
+    __builtin_nontemporal_store(vs, rk + r);
+    __builtin_nontemporal_store(od > 0 ? (S) ((double) vs / (double) od) : (S) 0, contrib_next_owned + r);
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -322,7 +329,7 @@ __device__ __forceinline__ void pr_block_body(pr_smem<S, ITEMS>& sm, const S* s_
 
     __syncthreads();  // previous pass done with LDS (and s_hot visible)
     if (tid == 0) sm.nlong = 0;
-    for (int i = tid; i < nr; i += THREADS) sm.rb[i] = rb[r0 + i];   // r1 <= rows, rb has rows+1 entries
+    for (int i = tid; i < nr; i += THREADS) sm.rb[i] = __builtin_nontemporal_load(rb + r0 + i);   // r1 <= rows, rb has rows+1 entries
 
     // ---- gather: coalesced index stream, random contribution reads, staged in LDS ----
     {
@@ -415,12 +422,13 @@ pr_step_kernel(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
                const int32_t* __restrict__ outdeg, S* __restrict__ rk,
                const S* __restrict__ contrib, S* __restrict__ contrib_next_owned,
                double base, double d,
-               double* __restrict__ part_first, double* __restrict__ part_last, double* __restrict__ diff_part) {
+               double* __restrict__ part_first, double* __restrict__ part_last, double* __restrict__ diff_part,
+               int64_t ncontrib) {
     __shared__ pr_smem<S, ITEMS> sm;
     __shared__ double s_red[THREADS / 64];
     __shared__ S s_hot[HOT > 0 ? HOT : 1];
     if (HOT > 0) {
-        for (int i = threadIdx.x; i < HOT; i += THREADS) s_hot[i] = contrib[i];
+        for (int i = threadIdx.x; i < HOT; i += THREADS) s_hot[i] = i < ncontrib ? contrib[i] : (S) 0;
     }
     out_final<S> out{rk, outdeg, contrib_next_owned, base, d, part_first, part_last};
     for (int64_t k = blockIdx.x; k < nblk; k += gridDim.x) {
@@ -439,26 +447,37 @@ __device__ __forceinline__ int pr_xcc_id() {
 // XCD-sliced variant: persistent workgroups; a workgroup on XCD x claims merge-path blocks of
 // slice x % ns from a queue (and steals from the other slices once its own is drained, which
 // only costs locality).  Row sums go to partial[slice][row]; pr_combine_kernel adds the slices.
-template <typename S, int THREADS, int ITEMS, bool NT>
+template <typename S, int THREADS, int ITEMS, bool NT, int ABL = 0>
 __global__ void __launch_bounds__(THREADS)
 pr_sliced_kernel(pr_sliced_args a, int64_t rows, const S* __restrict__ contrib) {
     __shared__ pr_smem<S, ITEMS> sm;
     __shared__ long long s_k;
     __shared__ int s_sl;
     const int home = pr_xcc_id() % a.ns;
-    int first_try = 0;   // slices before this offset are known to be drained
+    // thread 0 owns the dequeue state: a claimed chunk [k_next, k_end) of slice `cur`
+    long long k_next = 0, k_end = 0;
+    int cur = home, first_try = 0;   // slices before offset first_try (from home) are drained
     for (;;) {
         if (threadIdx.x == 0) {
             long long k = -1;
-            int sl = home;
-            for (int t = first_try; t < a.ns; t++) {
-                sl = (home + t) % a.ns;
-                unsigned int kk = atomicAdd(&a.queue[sl], 1u);
-                if ((int64_t) kk < a.s[sl].nblk) { k = (long long) kk; first_try = t; break; }
-                first_try = t + 1;
+            if (k_next < k_end) k = k_next++;
+            else {
+                for (int t = first_try; t < a.ns; t++) {
+                    cur = (home + t) % a.ns;
+                    const long long nb = a.s[cur].nblk;
+                    long long kk = (long long) atomicAdd(&a.queue[cur * PR_QUEUE_STRIDE], (unsigned int) PR_QUEUE_CHUNK);
+                    if (kk < nb) {
+                        k = kk;
+                        k_next = kk + 1;
+                        k_end = kk + PR_QUEUE_CHUNK < nb ? kk + PR_QUEUE_CHUNK : nb;
+                        first_try = t;
+                        break;
+                    }
+                    first_try = t + 1;
+                }
             }
             s_k = k;
-            s_sl = sl;
+            s_sl = cur;
         }
         __syncthreads();
         const long long k = s_k;
@@ -467,8 +486,305 @@ pr_sliced_kernel(pr_sliced_args a, int64_t rows, const S* __restrict__ contrib) 
         const pr_slice_desc& sd = a.s[sl];
         out_partial<S> out{(S*) sd.partial, sd.part_first, sd.part_last};
         double diff_acc = 0.0;
-        pr_block_body<S, THREADS, ITEMS, 0, NT>(sm, (const S*) nullptr, sd.blk, (int64_t) k, rows, sd.rb, sd.ridx, contrib, out, diff_acc);
+        pr_block_body<S, THREADS, ITEMS, 0, NT, out_partial<S>, ABL>(sm, (const S*) nullptr, sd.blk, (int64_t) k, rows, sd.rb, sd.ridx, contrib, out, diff_acc);
         __syncthreads();   // s_k / s_sl are rewritten by thread 0 at the top
+    }
+}
+
+// ======================================================================================
+// Wave-worker formulation (GMX_PR_WAVE): every WAVE is an independent worker that walks
+// merge-path blocks of PRW_ITEMS items; there is no workgroup barrier in the loop, the row
+// starts / outdeg / old rank of a block live in registers, the next block's index slice is
+// prefetched while the current block is reduced, and the per-wave |val-rank| partial stays in a
+// register until the end.  A workgroup only shares the optional LDS tile of hot contributions.
+// ======================================================================================
+#define PRW_ITEMS 512
+#define PRW_PER (PRW_ITEMS / 64)
+#define PRW_ROWU ((PRW_ITEMS + 1 + 63) / 64)
+#define PRW_LONG 32
+
+template <typename S>
+struct prw_lds {
+    S val[PRW_ITEMS];
+    int32_t rb[PRW_ITEMS + 2];
+};
+
+__device__ __forceinline__ double wave_allsum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <typename S>
+struct prw_final {
+    S* rk;
+    S* next_owned;
+    double base, d;
+    double* part_first;
+    double* part_last;
+    static constexpr bool needs_vertex_data = true;
+    __device__ __forceinline__ void row(int64_t r, double sum, int32_t od, S old, double& diff_acc) const {
+        if (od < 0) return;   // padding row
+        double val = base + d * sum;
+        S vs = (S) val;
+        diff_acc += fabs((double) vs - (double) old);
+        __builtin_nontemporal_store(vs, rk + r);
+        __builtin_nontemporal_store(od > 0 ? (S) ((double) vs / (double) od) : (S) 0, next_owned + r);
+    }
+};
+template <typename S>
+struct prw_partial {
+    S* partial;
+    double* part_first;
+    double* part_last;
+    static constexpr bool needs_vertex_data = false;
+    __device__ __forceinline__ void row(int64_t r, double sum, int32_t, S, double&) const { partial[r] = (S) sum; }
+};
+
+// Consume one block whose index slice is already in ix[] (prefetched); prefetch the next block's
+// slice (ridx_n + e0n, nen entries) into ixn[] behind the gathers.  hot_lim == 0 disables the tile.
+template <typename S, bool NT, typename OUT, int ABL>
+__device__ __forceinline__ void prw_block(prw_lds<S>* __restrict__ w, const S* __restrict__ s_hot, int hot_lim,
+                                          int hot_shift, int hot_sl_shift,
+                                          int64_t k, pr_blk b0, pr_blk b1, int64_t rows,
+                                          const int32_t* __restrict__ rb, const int32_t* __restrict__ outdeg,
+                                          const S* __restrict__ rk_old, const S* __restrict__ contrib,
+                                          const int32_t (&ix)[PRW_PER],
+                                          const int32_t* __restrict__ ridx_n, int e0n, int nen, int32_t (&ixn)[PRW_PER],
+                                          const OUT& out, double& diff_acc) {
+    const int lane = threadIdx.x & 63;
+    const int r0 = b0.r, e0 = b0.e, r1 = b1.r, e1 = b1.e;
+    const int ne = e1 - e0;
+    const int nr = r1 - r0 + 1;
+
+    // ---- issue: row starts (+ outdeg / old rank of the rows this block can finish) ----
+    int32_t rbv[PRW_ROWU], od[PRW_ROWU];
+    S old[PRW_ROWU];
+#pragma unroll
+    for (int u = 0; u < PRW_ROWU; u++) {
+        const int i = lane + 64 * u;
+        rbv[u] = 0;
+        od[u] = -1;
+        old[u] = (S) 0;
+        if (i < nr) {
+            rbv[u] = __builtin_nontemporal_load(rb + r0 + i);
+            if (OUT::needs_vertex_data && i < nr - 1) {
+                od[u] = __builtin_nontemporal_load(outdeg + r0 + i);
+                old[u] = __builtin_nontemporal_load(rk_old + r0 + i);
+            }
+        }
+    }
+    // ---- issue: gathers ----
+    S vv[PRW_PER];
+#pragma unroll
+    for (int u = 0; u < PRW_PER; u++) {
+        vv[u] = (S) 0;
+        const int32_t id = ix[u];
+        if (id >= 0) {
+            if (ABL == 1) vv[u] = (S) 1;
+            else if (ABL == 2) vv[u] = contrib[id & 1023];
+            else {
+                // tile slot of an id of the home slice: drop the slice bits above the run offset
+                const int q = ((id >> (PR_RUN_SHIFT + hot_sl_shift)) << PR_RUN_SHIFT) | (id & ((1 << PR_RUN_SHIFT) - 1));
+                if (hot_lim > 0 && (hot_shift ? q : id) < hot_lim) vv[u] = s_hot[hot_shift ? q : id];
+                else vv[u] = contrib[id];
+            }
+        }
+    }
+    // ---- prefetch the next block's index slice ----
+#pragma unroll
+    for (int u = 0; u < PRW_PER; u++) {
+        const int j = lane + 64 * u;
+        ixn[u] = -1;
+        if (j < nen) ixn[u] = NT ? __builtin_nontemporal_load(ridx_n + e0n + j) : ridx_n[e0n + j];
+    }
+    // ---- stage in this wave's LDS ----
+#pragma unroll
+    for (int u = 0; u < PRW_ROWU; u++) {
+        const int i = lane + 64 * u;
+        if (i < nr) w->rb[i] = rbv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < PRW_PER; u++) {
+        const int j = lane + 64 * u;
+        if (j < ne) w->val[j] = vv[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible to all its lanes
+    __builtin_amdgcn_wave_barrier();
+
+    const bool first_started_here = (w->rb[0] >= e0);
+#pragma unroll
+    for (int u = 0; u < PRW_ROWU; u++) {
+        if (64 * u >= nr) break;
+        const int i = lane + 64 * u;
+        const bool valid = i < nr;
+        int lo = 0, hi = 0;
+        if (valid) {
+            lo = rbv[u] - e0;
+            if (lo < 0) lo = 0;
+            hi = (i < nr - 1) ? w->rb[i + 1] - e0 : ne;
+        }
+        const bool is_long = valid && (hi - lo > PRW_LONG);
+        double sum = 0.0;
+        if (valid && !is_long)
+            for (int j = lo; j < hi; j++) sum += (double) w->val[j];
+        unsigned long long m = __ballot(is_long);
+        while (m) {   // long rows: the whole wave strides over the segment
+            const int l = __ffsll((long long) m) - 1;
+            m &= m - 1;
+            const int llo = __shfl(lo, l, 64), lhi = __shfl(hi, l, 64);
+            double t = 0.0;
+            for (int j = llo + lane; j < lhi; j += 64) t += (double) w->val[j];
+            t = wave_allsum(t);
+            if (lane == l) sum = t;
+        }
+        if (valid) {
+            const bool started = (i > 0) || first_started_here;
+            const bool finished = (i < nr - 1);
+            if (!started) out.part_first[k] = sum;
+            else if (finished) out.row((int64_t) r0 + i, sum, od[u], old[u], diff_acc);
+            else if (r0 + i < rows && hi > lo) out.part_last[k] = sum;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();   // all lanes done reading before the next block overwrites the LDS slice
+}
+
+// Unsliced: wave w of the grid handles blocks w, w + W, w + 2W, ... (static, deterministic).
+template <typename S, int WAVES, int HOT, bool NT, int ABL>
+__global__ void __launch_bounds__(WAVES * 64)
+pr_wave_kernel(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
+               const int32_t* __restrict__ rb, const int32_t* __restrict__ ridx,
+               const int32_t* __restrict__ outdeg, S* __restrict__ rk,
+               const S* __restrict__ contrib, S* __restrict__ contrib_next_owned,
+               double base, double d,
+               double* __restrict__ part_first, double* __restrict__ part_last, double* __restrict__ diff_part,
+               int64_t ncontrib) {
+    __shared__ prw_lds<S> lds[WAVES];
+    __shared__ S s_hot[HOT > 0 ? HOT : 1];
+    if (HOT > 0) {
+        for (int i = threadIdx.x; i < HOT; i += WAVES * 64) s_hot[i] = i < ncontrib ? contrib[i] : (S) 0;
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t W = (int64_t) gridDim.x * WAVES;
+    int64_t k = (int64_t) blockIdx.x * WAVES + wv;
+    prw_lds<S>* w = &lds[wv];
+    prw_final<S> out{rk, contrib_next_owned, base, d, part_first, part_last};
+    double diff_acc = 0.0;
+    int32_t ix[PRW_PER], ixn[PRW_PER];
+    pr_blk b0 = {0, 0}, b1 = {0, 0};
+    if (k < nblk) {
+        b0 = blk[k];
+        b1 = blk[k + 1];
+#pragma unroll
+        for (int u = 0; u < PRW_PER; u++) {
+            const int j = lane + 64 * u;
+            ix[u] = -1;
+            if (j < b1.e - b0.e) ix[u] = NT ? __builtin_nontemporal_load(ridx + b0.e + j) : ridx[b0.e + j];
+        }
+    }
+    while (k < nblk) {
+        const int64_t kn = k + W;
+        pr_blk n0 = {0, 0}, n1 = {0, 0};
+        if (kn < nblk) {
+            n0 = blk[kn];
+            n1 = blk[kn + 1];
+        }
+        prw_block<S, NT, prw_final<S>, ABL>(w, s_hot, HOT, 0, 0, k, b0, b1, rows, rb, outdeg, rk, contrib, ix,
+                                             ridx, n0.e, n1.e - n0.e, ixn, out, diff_acc);
+        k = kn;
+        b0 = n0;
+        b1 = n1;
+#pragma unroll
+        for (int u = 0; u < PRW_PER; u++) ix[u] = ixn[u];
+    }
+    diff_acc = wave_sum(diff_acc);
+    if (lane == 0) diff_part[(int64_t) blockIdx.x * WAVES + wv] = diff_acc;
+}
+
+// Sliced: waves on XCD x claim chunks of slice x % ns (stealing from the others when drained).
+template <typename S, int WAVES, int HOT, bool NT, int ABL>
+__global__ void __launch_bounds__(WAVES * 64)
+pr_wave_sliced_kernel(pr_sliced_args a, int64_t rows, const S* __restrict__ contrib, int ns_shift) {
+    __shared__ prw_lds<S> lds[WAVES];
+    __shared__ S s_hot[HOT > 0 ? HOT : 1];
+    const int home = pr_xcc_id() % a.ns;
+    if (HOT > 0) {
+        // tile slot q <-> id ((q >> RUN) * ns + home) << RUN | (q & (RUN-1)): the hottest ids of the home slice
+        for (int q = threadIdx.x; q < HOT; q += WAVES * 64) {
+            const int64_t id = ((((int64_t) q >> PR_RUN_SHIFT) * a.ns + home) << PR_RUN_SHIFT) | (q & ((1 << PR_RUN_SHIFT) - 1));
+            s_hot[q] = id < rows ? contrib[id] : (S) 0;
+        }
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    prw_lds<S>* w = &lds[wv];
+    double unused = 0.0;
+    int32_t ix[PRW_PER], ixn[PRW_PER];
+
+    // dequeue state (wave-uniform; lane 0 performs the atomic, the result is broadcast)
+    long long k_next = 0, k_end = 0;
+    int cur = home, first_try = 0;
+    auto claim = [&](long long& k_out, int& sl_out) {
+        long long k = -1;
+        if (k_next < k_end) k = k_next++;
+        else {
+            for (int t = first_try; t < a.ns; t++) {
+                cur = (home + t) % a.ns;
+                const long long nb = a.s[cur].nblk;
+                unsigned int kk0 = 0;
+                if (lane == 0) kk0 = atomicAdd(&a.queue[cur * PR_QUEUE_STRIDE], (unsigned int) PRW_QUEUE_CHUNK);
+                const long long kk = (long long) (unsigned int) __builtin_amdgcn_readfirstlane((int) kk0);
+                if (kk < nb) {
+                    k = kk;
+                    k_next = kk + 1;
+                    k_end = kk + PRW_QUEUE_CHUNK < nb ? kk + PRW_QUEUE_CHUNK : nb;
+                    first_try = t;
+                    break;
+                }
+                first_try = t + 1;
+            }
+        }
+        k_out = k;
+        sl_out = cur;
+    };
+
+    long long k, kn;
+    int sl, sln;
+    claim(k, sl);
+    pr_blk b0 = {0, 0}, b1 = {0, 0};
+    if (k >= 0) {
+        b0 = a.s[sl].blk[k];
+        b1 = a.s[sl].blk[k + 1];
+        const int32_t* ridx = a.s[sl].ridx;
+#pragma unroll
+        for (int u = 0; u < PRW_PER; u++) {
+            const int j = lane + 64 * u;
+            ix[u] = -1;
+            if (j < b1.e - b0.e) ix[u] = NT ? __builtin_nontemporal_load(ridx + b0.e + j) : ridx[b0.e + j];
+        }
+    }
+    while (k >= 0) {
+        claim(kn, sln);
+        pr_blk n0 = {0, 0}, n1 = {0, 0};
+        if (kn >= 0) {
+            n0 = a.s[sln].blk[kn];
+            n1 = a.s[sln].blk[kn + 1];
+        }
+        const pr_slice_desc& sd = a.s[sl];
+        prw_partial<S> out{(S*) sd.partial, sd.part_first, sd.part_last};
+        prw_block<S, NT, prw_partial<S>, ABL>(w, s_hot, (HOT > 0 && sl == home) ? HOT : 0, 1, ns_shift, (int64_t) k, b0, b1, rows,
+                                               sd.rb, (const int32_t*) nullptr, (const S*) nullptr, contrib, ix,
+                                               kn >= 0 ? a.s[sln].ridx : sd.ridx, n0.e, n1.e - n0.e, ixn, out, unused);
+        k = kn;
+        sl = sln;
+        b0 = n0;
+        b1 = n1;
+#pragma unroll
+        for (int u = 0; u < PRW_PER; u++) ix[u] = ixn[u];
     }
 }
 
@@ -498,15 +814,15 @@ pr_fixup_kernel(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
                 const int32_t* __restrict__ rb, const int32_t* __restrict__ outdeg,
                 S* __restrict__ rk, S* __restrict__ contrib_next_owned, double base, double d,
                 double* __restrict__ part_first, double* __restrict__ part_last,
-                const double* __restrict__ diff_main, double* __restrict__ diff_out) {
+                const double* __restrict__ diff_main, int64_t n_main, double* __restrict__ diff_out) {
     __shared__ double s_red[256 / 64];
     int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     double diff_acc = 0.0;
     if (k < nblk) {
         out_final<S> out{rk, outdeg, contrib_next_owned, base, d, part_first, part_last};
         pr_fixup_one<S>(blk, nblk, rows, rb, k, out, diff_acc);
-        diff_acc += diff_main[k];   // fold in the main kernel's workgroup partial (fixed order)
     }
+    if (k < n_main) diff_acc += diff_main[k];   // fold in the main kernel's partials (fixed order)
     pr_block_diff<256>(diff_acc, s_red, diff_out + blockIdx.x);
 }
 
@@ -591,7 +907,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
     p->V = g->V;
     const bool relabel = (options & GMX_PR_RELABEL) != 0;
     if ((options & GMX_PR_SLICED) && relabel) {
-        p->ns = PR_MAX_SLICES;
+        p->ns = 4;   // measured best on RMAT-26 (profiles/): 2 XCD L2s share a slice
         const char* ev = getenv("GMX_PR_SLICES");
         if (ev && atoi(ev) >= 1 && atoi(ev) <= PR_MAX_SLICES) p->ns = atoi(ev);
     }
@@ -615,9 +931,11 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
         p->rows_real = hi > p->row_lo ? hi - p->row_lo : 0;
     }
     p->rows = p->ns > 0 ? p->slice : p->rows_real;
-    p->hot = (options & GMX_PR_HOT_LDS) != 0 && relabel && nranks == 1 && p->ns == 0;
+    p->wave = (options & GMX_PR_WAVE) != 0;
+    p->hot = (options & GMX_PR_HOT_LDS) != 0 && relabel && nranks == 1 && (p->ns == 0 || p->wave);
     p->threads = p->hot ? 1024 : 256;
-    p->items = p->hot ? 4096 : 2048;
+    p->items = p->wave ? PRW_ITEMS : (p->hot ? 4096 : 2048);
+    if (!p->hot && p->ns == 0 && getenv("GMX_PR_ITEMS") && atoi(getenv("GMX_PR_ITEMS")) == 4096) p->items = 4096;   // development only
 
     const int64_t V = g->V, E = g->E;
     hipStream_t s = 0;
@@ -719,7 +1037,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 p->sl_nblk_total = blk_off[ns];
                 size_t npart = (size_t) (p->sl_nblk_total ? p->sl_nblk_total : 1);
                 if ((st = p->sl_blk.alloc(npart)) || (st = p->sl_part_first.alloc(npart)) || (st = p->sl_part_last.alloc(npart)) ||
-                    (st = p->sl_partial.alloc((size_t) ns * (rows ? rows : 1) * elem_bytes)) || (st = p->sl_queue.alloc(PR_MAX_SLICES))) break;
+                    (st = p->sl_partial.alloc((size_t) ns * (rows ? rows : 1) * elem_bytes)) || (st = p->sl_queue.alloc(PR_MAX_SLICES * PR_QUEUE_STRIDE))) break;
                 memset(&p->sl, 0, sizeof(p->sl));
                 p->sl.ns = ns;
                 p->sl.queue = p->sl_queue.p;
@@ -753,12 +1071,12 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
             hipLaunchKernelGGL(pr_blocks_kernel, dim3(grid_for(p->nblk + 1, 256, 1 << 30)), dim3(256), 0, s,
                                p->rb, p->rows, p->El, p->items, p->nblk, p->blk.p);
         size_t nb = (size_t) (p->nblk ? p->nblk : 1);
-        if ((st = p->part_first.alloc(nb)) || (st = p->part_last.alloc(nb)) || (st = p->diff_part.alloc(2 * nb)) ||
+        if ((st = p->part_first.alloc(nb)) || (st = p->part_last.alloc(nb)) || (st = p->diff_part.alloc(2 * nb + 4096)) ||
             (st = p->diff.alloc(1)) || (st = p->rk.alloc((size_t) (p->rows ? p->rows : 1) * elem_bytes)) ||
             (st = p->contrib[0].alloc((size_t) p->Vpad * elem_bytes)) || (st = p->contrib[1].alloc((size_t) p->Vpad * elem_bytes))) break;
         if (hipMemset(p->contrib[0].p, 0, (size_t) p->Vpad * elem_bytes) != hipSuccess ||
             hipMemset(p->contrib[1].p, 0, (size_t) p->Vpad * elem_bytes) != hipSuccess ||
-            hipMemset(p->diff_part.p, 0, 2 * nb * sizeof(double)) != hipSuccess ||
+            hipMemset(p->diff_part.p, 0, (2 * nb + 4096) * sizeof(double)) != hipSuccess ||
             hipMemset(p->diff.p, 0, sizeof(double)) != hipSuccess ||
             hipDeviceSynchronize() != hipSuccess) { gmx_set_error("pr plan: memset failed"); st = GMX_ERR_HIP; break; }
         hipDeviceProp_t prop;
@@ -795,33 +1113,68 @@ extern "C" int gmx_pr_reset(gmx_pr_t* p, double d) {
     return GMX_OK;
 }
 
+template <typename S>
+static void launch_fixup(gmx_pr* p, hipStream_t s, int64_t n_main);
+
 template <typename S, int THREADS, int ITEMS, int HOT>
 static void launch_step(gmx_pr* p, hipStream_t s, int grid) {
     const double N = (double) p->V;
     const double base = (1 - p->d) / N;
     S* next_owned = (S*) p->contrib[1 - p->cur].p + p->row_lo;
     static const int abl = getenv("GMX_PR_ABLATE") ? atoi(getenv("GMX_PR_ABLATE")) : 0;   // development only
-    pr_ev_begin(p, s);
     if (abl == 1 || abl == 2) {
         if (abl == 1)
             hipLaunchKernelGGL((pr_step_kernel<S, THREADS, ITEMS, HOT, true, 1>), dim3(grid), dim3(THREADS), 0, s,
                                p->blk.p, p->nblk, p->rows, p->rb, p->ridx, p->outdeg.p, (S*) p->rk.p,
                                (const S*) p->contrib[p->cur].p, next_owned, base, p->d,
-                               p->part_first.p, p->part_last.p, p->diff_part.p);
+                               p->part_first.p, p->part_last.p, p->diff_part.p, p->Vpad);
         else
             hipLaunchKernelGGL((pr_step_kernel<S, THREADS, ITEMS, HOT, true, 2>), dim3(grid), dim3(THREADS), 0, s,
                                p->blk.p, p->nblk, p->rows, p->rb, p->ridx, p->outdeg.p, (S*) p->rk.p,
                                (const S*) p->contrib[p->cur].p, next_owned, base, p->d,
-                               p->part_first.p, p->part_last.p, p->diff_part.p);
+                               p->part_first.p, p->part_last.p, p->diff_part.p, p->Vpad);
     } else
     hipLaunchKernelGGL((pr_step_kernel<S, THREADS, ITEMS, HOT, true>), dim3(grid), dim3(THREADS), 0, s,
                        p->blk.p, p->nblk, p->rows, p->rb, p->ridx, p->outdeg.p, (S*) p->rk.p,
                        (const S*) p->contrib[p->cur].p, next_owned, base, p->d,
-                       p->part_first.p, p->part_last.p, p->diff_part.p);
-    pr_ev_end(p, s);
-    hipLaunchKernelGGL(pr_fixup_kernel<S>, dim3((unsigned) ((p->nblk + 255) / 256)), dim3(256), 0, s,
+                       p->part_first.p, p->part_last.p, p->diff_part.p, p->Vpad);
+    launch_fixup<S>(p, s, p->nblk);
+}
+
+template <typename S>
+static void launch_fixup(gmx_pr* p, hipStream_t s, int64_t n_main) {
+    const double N = (double) p->V;
+    const double base = (1 - p->d) / N;
+    S* next_owned = (S*) p->contrib[1 - p->cur].p + p->row_lo;
+    const int64_t n = p->nblk > n_main ? p->nblk : n_main;
+    p->n_fix_blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(pr_fixup_kernel<S>, dim3((unsigned) p->n_fix_blocks), dim3(256), 0, s,
                        p->blk.p, p->nblk, p->rows, p->rb, p->outdeg.p, (S*) p->rk.p, next_owned, base, p->d,
-                       p->part_first.p, p->part_last.p, (const double*) p->diff_part.p, p->diff_part.p + p->nblk);
+                       p->part_first.p, p->part_last.p, (const double*) p->diff_part.p, n_main, p->diff_part.p + p->nblk + 4096);
+}
+
+template <typename S, int WAVES, int HOT>
+static void launch_wave(gmx_pr* p, hipStream_t s) {
+    const double N = (double) p->V;
+    const double base = (1 - p->d) / N;
+    S* next_owned = (S*) p->contrib[1 - p->cur].p + p->row_lo;
+    static const int abl = getenv("GMX_PR_ABLATE") ? atoi(getenv("GMX_PR_ABLATE")) : 0;   // development only
+    static const int occ_env = getenv("GMX_PR_WG_PER_CU") ? atoi(getenv("GMX_PR_WG_PER_CU")) : 0;
+    int per_cu = HOT > 0 ? 1 : (occ_env > 0 ? occ_env : 5);
+    int64_t grid = (int64_t) p->persistent_grid * per_cu;
+    const int64_t need = (p->nblk + WAVES - 1) / WAVES;
+    if (grid > need) grid = need;
+    p->n_main = (int) (grid * WAVES);
+#define GMX_LAUNCH_WAVE(A)                                                                                         \
+    hipLaunchKernelGGL((pr_wave_kernel<S, WAVES, HOT, true, A>), dim3((unsigned) grid), dim3(WAVES * 64), 0, s,    \
+                       p->blk.p, p->nblk, p->rows, p->rb, p->ridx, p->outdeg.p, (S*) p->rk.p,                     \
+                       (const S*) p->contrib[p->cur].p, next_owned, base, p->d, p->part_first.p, p->part_last.p, \
+                       p->diff_part.p, p->Vpad)
+    if (abl == 1) GMX_LAUNCH_WAVE(1);
+    else if (abl == 2) GMX_LAUNCH_WAVE(2);
+    else GMX_LAUNCH_WAVE(0);
+#undef GMX_LAUNCH_WAVE
+    launch_fixup<S>(p, s, p->n_main);
 }
 
 template <typename S>
@@ -829,19 +1182,46 @@ static void launch_sliced(gmx_pr* p, hipStream_t s) {
     const double N = (double) p->V;
     const double base = (1 - p->d) / N;
     S* next_owned = (S*) p->contrib[1 - p->cur].p + p->row_lo;
-    (void) hipMemsetAsync(p->sl_queue.p, 0, sizeof(unsigned int) * PR_MAX_SLICES, s);
+    (void) hipMemsetAsync(p->sl_queue.p, 0, sizeof(unsigned int) * PR_MAX_SLICES * PR_QUEUE_STRIDE, s);
     int64_t maxblk = 0;
     for (int q = 0; q < p->ns; q++) maxblk = p->sl.s[q].nblk > maxblk ? p->sl.s[q].nblk : maxblk;
     int64_t total_blk = 0;
     for (int q = 0; q < p->ns; q++) total_blk += p->sl.s[q].nblk;
     int grid = p->persistent_grid * 8;   // 8 workgroups of 256 threads per CU
     if (grid > total_blk) grid = (int) total_blk;
-    if (grid > 0) {
-        pr_ev_begin(p, s);
+    if (grid > 0 && p->wave) {
+        static const int ablw = getenv("GMX_PR_ABLATE") ? atoi(getenv("GMX_PR_ABLATE")) : 0;   // development only
+        int ns_shift = 0;
+        while ((1 << ns_shift) < p->ns) ns_shift++;
+            if (p->hot && (1 << ns_shift) == p->ns) {
+            constexpr int HOTQ = sizeof(S) == 4 ? 22528 : 7168;
+            int64_t g2 = p->persistent_grid;
+            if (g2 * 16 > total_blk) g2 = (total_blk + 15) / 16;
+            hipLaunchKernelGGL((pr_wave_sliced_kernel<S, 16, HOTQ, true, 0>), dim3((unsigned) g2), dim3(1024), 0, s, p->sl, p->rows,
+                               (const S*) p->contrib[p->cur].p, ns_shift);
+        } else {
+            int64_t g2 = (int64_t) p->persistent_grid * 8;
+            if (g2 * 4 > total_blk) g2 = (total_blk + 3) / 4;
+            if (ablw == 1)
+                hipLaunchKernelGGL((pr_wave_sliced_kernel<S, 4, 0, true, 1>), dim3((unsigned) g2), dim3(256), 0, s, p->sl, p->rows,
+                                   (const S*) p->contrib[p->cur].p, ns_shift);
+            else
+                hipLaunchKernelGGL((pr_wave_sliced_kernel<S, 4, 0, true, 0>), dim3((unsigned) g2), dim3(256), 0, s, p->sl, p->rows,
+                                   (const S*) p->contrib[p->cur].p, ns_shift);
+        }
+            hipLaunchKernelGGL(pr_sliced_fixup_kernel<S>, dim3((unsigned) ((maxblk + 255) / 256), p->ns), dim3(256), 0, s, p->sl, p->rows);
+    } else if (grid > 0) {
+            static const int abl = getenv("GMX_PR_ABLATE") ? atoi(getenv("GMX_PR_ABLATE")) : 0;   // development only
+        if (abl == 1)
+            hipLaunchKernelGGL((pr_sliced_kernel<S, 256, 2048, true, 1>), dim3(grid), dim3(256), 0, s, p->sl, p->rows,
+                               (const S*) p->contrib[p->cur].p);
+        else if (abl == 2)
+            hipLaunchKernelGGL((pr_sliced_kernel<S, 256, 2048, true, 2>), dim3(grid), dim3(256), 0, s, p->sl, p->rows,
+                               (const S*) p->contrib[p->cur].p);
+        else
         hipLaunchKernelGGL((pr_sliced_kernel<S, 256, 2048, true>), dim3(grid), dim3(256), 0, s, p->sl, p->rows,
                            (const S*) p->contrib[p->cur].p);
-        pr_ev_end(p, s);
-        hipLaunchKernelGGL(pr_sliced_fixup_kernel<S>, dim3((unsigned) ((maxblk + 255) / 256), p->ns), dim3(256), 0, s, p->sl, p->rows);
+            hipLaunchKernelGGL(pr_sliced_fixup_kernel<S>, dim3((unsigned) ((maxblk + 255) / 256), p->ns), dim3(256), 0, s, p->sl, p->rows);
     }
     hipLaunchKernelGGL(pr_combine_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, p->sl, p->rows, p->outdeg.p, (S*) p->rk.p,
                        next_owned, base, p->d, p->diff_part.p);
@@ -850,12 +1230,22 @@ static void launch_sliced(gmx_pr* p, hipStream_t s) {
 extern "C" int gmx_pr_step(gmx_pr_t* p, void* stream) {
     GMX_REQUIRE(p, "pr is NULL");
     hipStream_t s = (hipStream_t) stream;
+    pr_ev_begin(p, s);   // one "launch" of the roofline = all kernels of one step
     if (p->ns > 0) {
         if (p->rows > 0) {
             if (p->elem == 4) launch_sliced<float>(p, s);
             else launch_sliced<double>(p, s);
             hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) p->diff_part.p, (int64_t) PR_COMBINE_GRID, p->diff.p);
         }
+    } else if (p->nblk > 0 && p->wave) {
+        if (p->hot) {
+            if (p->elem == 4) launch_wave<float, 16, 22528>(p, s);
+            else launch_wave<double, 16, 7168>(p, s);
+        } else {
+            if (p->elem == 4) launch_wave<float, 4, 0>(p, s);
+            else launch_wave<double, 4, 0>(p, s);
+        }
+        hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) (p->diff_part.p + p->nblk + 4096), p->n_fix_blocks, p->diff.p);
     } else if (p->nblk > 0) {
         if (p->hot) {
             int grid = p->persistent_grid < p->nblk ? p->persistent_grid : (int) p->nblk;
@@ -863,11 +1253,15 @@ extern "C" int gmx_pr_step(gmx_pr_t* p, void* stream) {
             else launch_step<double, 1024, 4096, 12288>(p, s, grid);
         } else {
             GMX_REQUIRE(p->nblk < (1LL << 31), "too many workgroups");
-            if (p->elem == 4) launch_step<float, 256, 2048, 0>(p, s, (int) p->nblk);
+            if (p->items == 4096) {
+                if (p->elem == 4) launch_step<float, 256, 4096, 0>(p, s, (int) p->nblk);
+                else launch_step<double, 256, 4096, 0>(p, s, (int) p->nblk);
+            } else if (p->elem == 4) launch_step<float, 256, 2048, 0>(p, s, (int) p->nblk);
             else launch_step<double, 256, 2048, 0>(p, s, (int) p->nblk);
         }
-        hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) (p->diff_part.p + p->nblk), (p->nblk + 255) / 256, p->diff.p);
+        hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) (p->diff_part.p + p->nblk + 4096), p->n_fix_blocks, p->diff.p);
     }
+    pr_ev_end(p, s);
     GMX_HIP(hipGetLastError());
     p->cur = 1 - p->cur;
     p->cnt++;
@@ -918,6 +1312,16 @@ extern "C" int gmx_pr_download(gmx_pr_t* p, void* rank_host) {
     return GMX_OK;
 }
 
+// Variant choice by size (measured, profiles/round1_*): below 2^25 vertices the contribution
+// vector mostly lives in L2 / Infinity Cache and the unsliced wave kernel with an LDS hot tile wins;
+// above, splitting the sources over the XCD L2s pays for its partial-sum pass.
+extern "C" uint32_t gmx_pr_default_options(int64_t V, int nranks) {
+    uint32_t o = GMX_PR_RELABEL | GMX_PR_WAVE;
+    if (nranks == 1) o |= GMX_PR_HOT_LDS;
+    if (V > (1LL << 25)) o |= GMX_PR_SLICED;
+    return o;
+}
+
 extern "C" int gmx_pr_timing(gmx_pr_t* p, int enable) {
     GMX_REQUIRE(p, "pr is NULL");
     p->timing = enable != 0;
@@ -941,7 +1345,10 @@ extern "C" int gmx_pr_kernel_time(gmx_pr_t* p, int32_t* launches, double* mean_m
 
 extern "C" const char* gmx_pr_kernel_name(gmx_pr_t* p) {
     if (!p) return "";
-    return p->ns > 0 ? "pr_sliced_kernel" : "pr_step_kernel";
+    if (p->ns > 0)
+        return p->wave ? "pr_wave_sliced_kernel+pr_sliced_fixup_kernel+pr_combine_kernel+pr_diff_reduce_kernel"
+                       : "pr_sliced_kernel+pr_sliced_fixup_kernel+pr_combine_kernel+pr_diff_reduce_kernel";
+    return p->wave ? "pr_wave_kernel+pr_fixup_kernel+pr_diff_reduce_kernel" : "pr_step_kernel+pr_fixup_kernel+pr_diff_reduce_kernel";
 }
 
 extern "C" int gmx_pr_work(gmx_pr_t* p, int64_t* edges, int64_t* rows, int64_t* algorithmic_bytes) {
@@ -960,7 +1367,7 @@ static int pagerank_entry(gmx_graph_t* g, double e, double d, int32_t max_iter, 
     if (stats) memset(stats, 0, sizeof(*stats));
     if (g->V == 0) return GMX_OK;
     gmx_pr_t* p = nullptr;
-    GMX_CHECK(gmx_pr_create(g, (int) sizeof(S), 0, 1, GMX_PR_RELABEL, &p));
+    GMX_CHECK(gmx_pr_create(g, (int) sizeof(S), 0, 1, gmx_pr_default_options(g->V, 1), &p));
     int st = gmx_pr_reset(p, d);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double diff = 0.0;

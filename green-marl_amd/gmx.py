@@ -17,6 +17,7 @@ GMX_GRAPH_NO_REVERSE = 0x2
 GMX_PR_RELABEL = 0x1
 GMX_PR_HOT_LDS = 0x2
 GMX_PR_SLICED = 0x4
+GMX_PR_WAVE = 0x8
 INT_MAX = 2147483647
 
 
@@ -46,7 +47,7 @@ EXPORTS = [
     "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_triangle_counting",
     "gmx_pr_create", "gmx_pr_free", "gmx_pr_reset", "gmx_pr_step", "gmx_pr_contrib_slice",
     "gmx_pr_contrib_full", "gmx_pr_diff_ptr", "gmx_pr_diff", "gmx_pr_download", "gmx_pr_work",
-    "gmx_pr_timing", "gmx_pr_kernel_time", "gmx_pr_kernel_name",
+    "gmx_pr_timing", "gmx_pr_kernel_time", "gmx_pr_kernel_name", "gmx_pr_default_options",
 ]
 
 _LIB = None
@@ -88,6 +89,8 @@ def lib():
         L.gmx_pr_diff.argtypes = [vp, vp, C.POINTER(C.c_double)]
         L.gmx_pr_download.argtypes = [vp, vp]
         L.gmx_pr_work.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+        L.gmx_pr_default_options.argtypes = [i64, C.c_int]
+        L.gmx_pr_default_options.restype = C.c_uint32
         L.gmx_pr_timing.argtypes = [vp, C.c_int]
         L.gmx_pr_kernel_time.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_double)]
         L.gmx_pr_kernel_name.argtypes = [vp]
@@ -224,6 +227,10 @@ class Graph:
         st = Stats()
         _ck(lib().gmx_triangle_counting(self._h, C.byref(t), C.byref(st)))
         return t.value, st.as_dict()
+
+
+def default_pr_options(V, nranks=1):
+    return int(lib().gmx_pr_default_options(V, nranks))
 
 
 class DevArray:

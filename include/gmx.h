@@ -132,7 +132,10 @@ int gmx_triangle_counting(gmx_graph_t* g, int64_t* count, gmx_stats_t* stats);
 /* options bit flags */
 #define GMX_PR_RELABEL   0x1u   /* degree-sorted internal numbering (default on in whole-kernel entries) */
 #define GMX_PR_HOT_LDS   0x2u   /* keep the hottest contributions in LDS */
+#define GMX_PR_WAVE      0x8u   /* wave-worker kernels (no workgroup barriers, register-resident row data, prefetch) */
 #define GMX_PR_SLICED    0x4u   /* split in-edges by source slice, one slice per XCD L2 (needs GMX_PR_RELABEL) */
+/* The option set the whole-kernel entries use for a graph of V vertices on nranks ranks. */
+uint32_t gmx_pr_default_options(int64_t V, int nranks);
 int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nranks, uint32_t options, gmx_pr_t** out);
 int gmx_pr_free(gmx_pr_t* p);
 int gmx_pr_reset(gmx_pr_t* p, double d);                 /* rank = 1/N, contrib = rank/outdeg, cnt = 0 */
@@ -150,13 +153,14 @@ int gmx_pr_diff(gmx_pr_t* p, void* stream, double* diff);
 /* Blocking: ranks of the owned rows scattered into rank_host[V] at original
  * vertex ids (other entries untouched). */
 int gmx_pr_download(gmx_pr_t* p, void* rank_host);
-/* Per-kernel timing of the dominant kernel (the row-reduction kernel of gmx_pr_step), with
- * hipEvents recorded on the stream the kernel is launched on.  enable != 0 starts a fresh
- * measurement; gmx_pr_kernel_time blocks until the recorded launches finished and returns
- * their count and mean duration (bench.py's roofline.achieved uses exactly this). */
+/* Device timing of the kernels of gmx_pr_step (the row-reduction kernel plus its small fix-up /
+ * combine / diff-reduce kernels: together they move the algorithmic bytes of one iteration), with
+ * hipEvents recorded on the stream they are launched on.  enable != 0 starts a fresh
+ * measurement; gmx_pr_kernel_time blocks until the recorded steps finished and returns their
+ * count and mean duration (bench.py's roofline.achieved uses exactly this). */
 int gmx_pr_timing(gmx_pr_t* p, int enable);
 int gmx_pr_kernel_time(gmx_pr_t* p, int32_t* launches, double* mean_ms);
-/* Name of the dominant kernel as rocprofv3 prints it (prefix match). */
+/* '+'-joined names of those kernels as rocprofv3 prints them (prefix match). */
 const char* gmx_pr_kernel_name(gmx_pr_t* p);
 /* Algorithmic bytes / edges one step of this rank processes. */
 int gmx_pr_work(gmx_pr_t* p, int64_t* edges, int64_t* rows, int64_t* algorithmic_bytes);
