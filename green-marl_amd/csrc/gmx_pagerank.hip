@@ -47,7 +47,10 @@ struct pr_slice_desc {
     const int32_t* ridx;
     double* part_first;
     double* part_last;
-    void* partial;   // [rows] row sums restricted to this slice (element type S)
+    void* partial;   // [rows of the rank] row sums restricted to this slice (element type S); rows the
+                     // slice has no edge for keep the 0 they were initialised with (the graph is static)
+    const int32_t* rowid;   // compact row -> local row: only rows with at least one edge in the slice are stored
+    int64_t crows;          // number of compact rows
 };
 struct pr_sliced_args {
     pr_slice_desc s[PR_MAX_SLICES];
@@ -91,7 +94,7 @@ struct gmx_pr {
     // XCD-sliced variant
     int ns = 0;
     pr_sliced_args sl;
-    dbuf<int32_t> sl_rb, sl_ridx;
+    dbuf<int32_t> sl_rb, sl_ridx, sl_rowid;
     dbuf<pr_blk> sl_blk;
     dbuf<double> sl_part_first, sl_part_last;
     dbuf<char> sl_partial;
@@ -220,23 +223,32 @@ __global__ void pr_slice_offsets_kernel(const uint8_t* __restrict__ sl_sorted, i
     off[t] = lo;
 }
 
-// vals = keys grouped by slice (stable), off[s] = start of slice s.  blockIdx.y = slice.
-__global__ void pr_slice_csr_kernel(const uint64_t* __restrict__ vals, const int64_t* __restrict__ off,
-                                    int64_t row_lo, int64_t rows, int32_t* __restrict__ rb_all, int32_t* __restrict__ ridx_all) {
-    const int sl = blockIdx.y;
-    const int64_t o0 = off[sl], o1 = off[sl + 1];
+// vals = keys grouped by slice (stable).  flag[i] = 1 where position i starts a new (slice,row) pair.
+__global__ void pr_slice_flag_kernel(const uint64_t* __restrict__ vals, const uint8_t* __restrict__ sl, int64_t n,
+                                     int32_t* __restrict__ flag, int32_t* __restrict__ ridx_all) {
     int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t) gridDim.x * blockDim.x;
-    for (int64_t e = o0 + i; e < o1; e += stride) ridx_all[e] = (int32_t) (uint32_t) (vals[e] & 0xffffffffu);
-    int32_t* rb = rb_all + (int64_t) sl * (rows + 1);
-    for (int64_t r = i; r <= rows; r += stride) {
-        uint64_t target = (uint64_t) (row_lo + r) << 32;
-        int64_t lo = o0, hi = o1;
-        while (lo < hi) {
-            int64_t mid = (lo + hi) >> 1;
-            if (vals[mid] < target) lo = mid + 1; else hi = mid;
-        }
-        rb[r] = (int32_t) (lo - o0);
+    for (; i < n; i += stride) {
+        const uint64_t kx = vals[i];
+        ridx_all[i] = (int32_t) (uint32_t) (kx & 0xffffffffu);
+        flag[i] = (i == 0 || sl[i] != sl[i - 1] || (vals[i - 1] >> 32) != (kx >> 32)) ? 1 : 0;
+    }
+}
+
+// pos = exclusive scan of flag.  Pair p of slice s (global pair index pos[i]) gets
+//   rowid[p] = row - row_lo,  rb[p + s] = i - off[s]   (each slice's rb has one extra, terminating entry).
+__global__ void pr_slice_pairs_kernel(const uint64_t* __restrict__ vals, const uint8_t* __restrict__ sl,
+                                      const int32_t* __restrict__ flag, const int32_t* __restrict__ pos,
+                                      const int64_t* __restrict__ off, int64_t n, int64_t row_lo,
+                                      int32_t* __restrict__ rowid_all, int32_t* __restrict__ rb_all) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        if (!flag[i]) continue;
+        const int s = sl[i];
+        const int64_t p = pos[i];
+        rowid_all[p] = (int32_t) ((int64_t) (vals[i] >> 32) - row_lo);
+        rb_all[p + s] = (int32_t) (i - off[s]);
     }
 }
 
@@ -297,9 +309,10 @@ struct out_final {
 template <typename S>
 struct out_partial {
     S* partial;
+    const int32_t* rowid;
     double* part_first;
     double* part_last;
-    __device__ __forceinline__ void row(int64_t r, double sum, double&) const { partial[r] = (S) sum; }
+    __device__ __forceinline__ void row(int64_t r, double sum, double&) const { partial[rowid[r]] = (S) sum; }
 };
 
 template <typename S, int ITEMS>
@@ -484,9 +497,9 @@ pr_sliced_kernel(pr_sliced_args a, int64_t rows, const S* __restrict__ contrib) 
         const int sl = s_sl;
         if (k < 0) break;
         const pr_slice_desc& sd = a.s[sl];
-        out_partial<S> out{(S*) sd.partial, sd.part_first, sd.part_last};
+        out_partial<S> out{(S*) sd.partial, sd.rowid, sd.part_first, sd.part_last};
         double diff_acc = 0.0;
-        pr_block_body<S, THREADS, ITEMS, 0, NT, out_partial<S>, ABL>(sm, (const S*) nullptr, sd.blk, (int64_t) k, rows, sd.rb, sd.ridx, contrib, out, diff_acc);
+        pr_block_body<S, THREADS, ITEMS, 0, NT, out_partial<S>, ABL>(sm, (const S*) nullptr, sd.blk, (int64_t) k, sd.crows, sd.rb, sd.ridx, contrib, out, diff_acc);
         __syncthreads();   // s_k / s_sl are rewritten by thread 0 at the top
     }
 }
@@ -535,10 +548,13 @@ struct prw_final {
 template <typename S>
 struct prw_partial {
     S* partial;
+    const int32_t* rowid;
     double* part_first;
     double* part_last;
     static constexpr bool needs_vertex_data = false;
-    __device__ __forceinline__ void row(int64_t r, double sum, int32_t, S, double&) const { partial[r] = (S) sum; }
+    __device__ __forceinline__ void row(int64_t r, double sum, int32_t, S, double&) const {
+        partial[__builtin_nontemporal_load(rowid + r)] = (S) sum;
+    }
 };
 
 // Consume one block whose index slice is already in ix[] (prefetched); prefetch the next block's
@@ -775,8 +791,8 @@ pr_wave_sliced_kernel(pr_sliced_args a, int64_t rows, const S* __restrict__ cont
             n1 = a.s[sln].blk[kn + 1];
         }
         const pr_slice_desc& sd = a.s[sl];
-        prw_partial<S> out{(S*) sd.partial, sd.part_first, sd.part_last};
-        prw_block<S, NT, prw_partial<S>, ABL>(w, s_hot, (HOT > 0 && sl == home) ? HOT : 0, 1, ns_shift, (int64_t) k, b0, b1, rows,
+        prw_partial<S> out{(S*) sd.partial, sd.rowid, sd.part_first, sd.part_last};
+        prw_block<S, NT, prw_partial<S>, ABL>(w, s_hot, (HOT > 0 && sl == home) ? HOT : 0, 1, ns_shift, (int64_t) k, b0, b1, sd.crows,
                                                sd.rb, (const int32_t*) nullptr, (const S*) nullptr, contrib, ix,
                                                kn >= 0 ? a.s[sln].ridx : sd.ridx, n0.e, n1.e - n0.e, ixn, out, unused);
         k = kn;
@@ -833,8 +849,8 @@ __global__ void pr_sliced_fixup_kernel(pr_sliced_args a, int64_t rows) {
     int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= sd.nblk) return;
     double unused = 0.0;
-    out_partial<S> out{(S*) sd.partial, sd.part_first, sd.part_last};
-    pr_fixup_one<S>(sd.blk, sd.nblk, rows, sd.rb, k, out, unused);
+    out_partial<S> out{(S*) sd.partial, sd.rowid, sd.part_first, sd.part_last};
+    pr_fixup_one<S>(sd.blk, sd.nblk, sd.crows, sd.rb, k, out, unused);
 }
 
 // sum the slices in fixed order and apply the PageRank update (streaming, one thread per row)
@@ -1024,20 +1040,56 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 hipLaunchKernelGGL(pr_slice_offsets_kernel, dim3(1), dim3(64), 0, s, (const uint8_t*) sk2.p, El, ns, off.p);
                 int64_t hoff[PR_MAX_SLICES + 1];
                 if (hipMemcpy(hoff, off.p, sizeof(int64_t) * (ns + 1), hipMemcpyDeviceToHost) != hipSuccess) { gmx_set_error("pr plan: slice offsets copy failed"); st = GMX_ERR_HIP; break; }
-                if ((st = p->sl_rb.alloc((size_t) ns * (rows + 1))) || (st = p->sl_ridx.alloc((size_t) El))) break;
-                hipLaunchKernelGGL(pr_slice_csr_kernel, dim3(grid_for((El / ns > rows ? El / ns : rows) + 1), ns), dim3(256), 0, s,
-                                   (const uint64_t*) vals.p, (const int64_t*) off.p, p->row_lo, rows, p->sl_rb.p, p->sl_ridx.p);
+                // compact rows: one (slice,row) pair per row that has at least one edge in the slice
+                dbuf<int32_t> flag, pos;
+                if ((st = flag.alloc((size_t) El + 1)) || (st = pos.alloc((size_t) El + 1)) || (st = p->sl_ridx.alloc((size_t) El))) break;
+                hipLaunchKernelGGL(pr_slice_flag_kernel, dim3(grid_for(El)), dim3(256), 0, s, (const uint64_t*) vals.p,
+                                   (const uint8_t*) sk2.p, El, flag.p, p->sl_ridx.p);
+                int64_t npairs = 0;
+                int64_t pair_off[PR_MAX_SLICES + 1];
+                if (El > 0) {
+                    size_t tb = 0;
+                    he = rocprim::exclusive_scan(nullptr, tb, flag.p, pos.p, 0, (size_t) El, rocprim::plus<int32_t>(), s);
+                    dbuf<char> tmp2;
+                    if (he == hipSuccess && (st = tmp2.alloc(tb))) break;
+                    if (he == hipSuccess) he = rocprim::exclusive_scan((void*) tmp2.p, tb, flag.p, pos.p, 0, (size_t) El, rocprim::plus<int32_t>(), s);
+                    if (he == hipSuccess) he = hipStreamSynchronize(s);
+                    if (he != hipSuccess) { gmx_set_error("pr plan: pair scan failed: %s", hipGetErrorString(he)); st = GMX_ERR_HIP; break; }
+                    int32_t lastp = 0, lastf = 0;
+                    if (hipMemcpy(&lastp, pos.p + (El - 1), 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                        hipMemcpy(&lastf, flag.p + (El - 1), 4, hipMemcpyDeviceToHost) != hipSuccess) { gmx_set_error("pr plan: copy failed"); st = GMX_ERR_HIP; break; }
+                    npairs = (int64_t) lastp + lastf;
+                }
+                for (int q = 0; q <= ns; q++) {   // pairs before the first position of slice q
+                    pair_off[q] = npairs;
+                    if (hoff[q] < El) {
+                        int32_t v = 0;
+                        if (hipMemcpy(&v, pos.p + hoff[q], 4, hipMemcpyDeviceToHost) != hipSuccess) { gmx_set_error("pr plan: copy failed"); st = GMX_ERR_HIP; break; }
+                        pair_off[q] = v;
+                    }
+                }
+                if (st) break;
+                if ((st = p->sl_rb.alloc((size_t) npairs + ns + 1)) || (st = p->sl_rowid.alloc((size_t) (npairs ? npairs : 1)))) break;
+                hipLaunchKernelGGL(pr_slice_pairs_kernel, dim3(grid_for(El)), dim3(256), 0, s, (const uint64_t*) vals.p,
+                                   (const uint8_t*) sk2.p, (const int32_t*) flag.p, (const int32_t*) pos.p, (const int64_t*) off.p,
+                                   El, p->row_lo, p->sl_rowid.p, p->sl_rb.p);
                 int64_t nblk_s[PR_MAX_SLICES], blk_off[PR_MAX_SLICES + 1];
                 blk_off[0] = 0;
                 for (int q = 0; q < ns; q++) {
-                    int64_t tot = rows + (hoff[q + 1] - hoff[q]);
+                    const int64_t crows = pair_off[q + 1] - pair_off[q], es = hoff[q + 1] - hoff[q];
+                    const int32_t term = (int32_t) es;   // terminating rb entry of the slice
+                    if (hipMemcpy(p->sl_rb.p + pair_off[q + 1] + q, &term, 4, hipMemcpyHostToDevice) != hipSuccess) { gmx_set_error("pr plan: copy failed"); st = GMX_ERR_HIP; break; }
+                    int64_t tot = crows + es;
                     nblk_s[q] = (tot + p->items - 1) / p->items;
                     blk_off[q + 1] = blk_off[q] + nblk_s[q] + 1;
                 }
+                if (st) break;
                 p->sl_nblk_total = blk_off[ns];
                 size_t npart = (size_t) (p->sl_nblk_total ? p->sl_nblk_total : 1);
+                const size_t partial_bytes = (size_t) ns * (size_t) (rows ? rows : 1) * elem_bytes;
                 if ((st = p->sl_blk.alloc(npart)) || (st = p->sl_part_first.alloc(npart)) || (st = p->sl_part_last.alloc(npart)) ||
-                    (st = p->sl_partial.alloc((size_t) ns * (rows ? rows : 1) * elem_bytes)) || (st = p->sl_queue.alloc(PR_MAX_SLICES * PR_QUEUE_STRIDE))) break;
+                    (st = p->sl_partial.alloc(partial_bytes)) || (st = p->sl_queue.alloc(PR_MAX_SLICES * PR_QUEUE_STRIDE))) break;
+                if (hipMemset(p->sl_partial.p, 0, partial_bytes) != hipSuccess) { gmx_set_error("pr plan: memset failed"); st = GMX_ERR_HIP; break; }
                 memset(&p->sl, 0, sizeof(p->sl));
                 p->sl.ns = ns;
                 p->sl.queue = p->sl_queue.p;
@@ -1045,13 +1097,15 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                     pr_slice_desc& sd = p->sl.s[q];
                     sd.blk = p->sl_blk.p + blk_off[q];
                     sd.nblk = nblk_s[q];
-                    sd.rb = p->sl_rb.p + (int64_t) q * (rows + 1);
+                    sd.rb = p->sl_rb.p + pair_off[q] + q;
                     sd.ridx = p->sl_ridx.p + hoff[q];
                     sd.part_first = p->sl_part_first.p + blk_off[q];
                     sd.part_last = p->sl_part_last.p + blk_off[q];
                     sd.partial = p->sl_partial.p + (size_t) q * (size_t) rows * elem_bytes;
+                    sd.rowid = p->sl_rowid.p + pair_off[q];
+                    sd.crows = pair_off[q + 1] - pair_off[q];
                     hipLaunchKernelGGL(pr_blocks_kernel, dim3(grid_for(nblk_s[q] + 1, 256, 1 << 30)), dim3(256), 0, s,
-                                       sd.rb, rows, hoff[q + 1] - hoff[q], p->items, nblk_s[q], p->sl_blk.p + blk_off[q]);
+                                       sd.rb, sd.crows, hoff[q + 1] - hoff[q], p->items, nblk_s[q], p->sl_blk.p + blk_off[q]);
                 }
                 if (hipStreamSynchronize(s) != hipSuccess) { gmx_set_error("pr plan: slice csr failed"); st = GMX_ERR_HIP; break; }
             } else {
