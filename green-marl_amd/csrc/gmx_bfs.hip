@@ -229,11 +229,27 @@ extern "C" int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host,
     int32_t* next_q = q1.p;
     bool frontier_is_bitmap = false;     // true: frontier lives in bm0 (bottom-up produced it)
     const int64_t bu_threshold = V / 20; // RRD_THRESHOLD = 0.05 (gm_bfs_template.h:359)
+    int64_t explored = 0;                // out-edges of the frontiers expanded so far
 
     while (cur_count > 0) {
         bfs_counters zero = {0, edges};
         GMX_HIP(hipMemcpy(ctr.p, &zero, sizeof(zero), hipMemcpyHostToDevice));
-        const bool bottom_up = can_bottom_up && cur_count > bu_threshold;
+        // Direction choice (Beamer's rule with the reference's 5 % vertex threshold as a second trigger,
+        // gm_bfs_template.h:359-415): a queue frontier goes bottom-up when its out-edges exceed 1/14 of the
+        // edges not yet explored; a bitmap frontier returns to the queue when it shrinks below V/24.
+        int64_t m_f = 0;
+        bool bottom_up;
+        if (frontier_is_bitmap) bottom_up = cur_count > V / 24;
+        else {
+            hipLaunchKernelGGL(bfs_degree_kernel, dim3(grid_for(cur_count)), dim3(BFS_THREADS), 0, 0, g->begin.p, cur_q, cur_count, deg.p);
+            size_t tb = scan_bytes;
+            GMX_HIP(rocprim::inclusive_scan(scan_tmp.p, tb, deg.p, off.p + 1, (size_t) cur_count, rocprim::plus<int64_t>(), 0));
+            GMX_HIP(hipMemsetAsync(off.p, 0, sizeof(int64_t), 0));
+            GMX_HIP(hipMemcpy(&m_f, off.p + cur_count, sizeof(int64_t), hipMemcpyDeviceToHost));
+            const int64_t unexplored = g->E - explored;
+            bottom_up = can_bottom_up && (cur_count > bu_threshold || m_f > unexplored / 14);
+            explored += m_f;
+        }
         if (bottom_up) {
             if (!frontier_is_bitmap) {
                 GMX_HIP(hipMemsetAsync(bm0.p, 0, bmw * 4, 0));
@@ -245,21 +261,17 @@ extern "C" int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host,
             uint32_t* t = bm0.p; bm0.p = bm1.p; bm1.p = t;
             frontier_is_bitmap = true;
         } else {
-            if (frontier_is_bitmap) {  // came back from bottom-up: rebuild the queue
+            if (frontier_is_bitmap) {  // came back from bottom-up: rebuild the queue, then its edge offsets
                 GMX_HIP(hipMemsetAsync(qcount.p, 0, sizeof(unsigned long long), 0));
                 hipLaunchKernelGGL(bfs_bitmap_to_queue_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, bm0.p, V, cur_q, qcount.p);
                 frontier_is_bitmap = false;
-            }
-            // degrees -> exclusive scan -> merge-path expansion
-            hipLaunchKernelGGL(bfs_degree_kernel, dim3(grid_for(cur_count)), dim3(BFS_THREADS), 0, 0, g->begin.p, cur_q, cur_count, deg.p);
-            GMX_HIP(hipMemsetAsync(off.p + cur_count, 0, sizeof(int64_t), 0));
-            {
+                hipLaunchKernelGGL(bfs_degree_kernel, dim3(grid_for(cur_count)), dim3(BFS_THREADS), 0, 0, g->begin.p, cur_q, cur_count, deg.p);
                 size_t tb = scan_bytes;
                 GMX_HIP(rocprim::inclusive_scan(scan_tmp.p, tb, deg.p, off.p + 1, (size_t) cur_count, rocprim::plus<int64_t>(), 0));
                 GMX_HIP(hipMemsetAsync(off.p, 0, sizeof(int64_t), 0));
+                GMX_HIP(hipMemcpy(&m_f, off.p + cur_count, sizeof(int64_t), hipMemcpyDeviceToHost));
+                explored += m_f;
             }
-            int64_t m_f = 0;
-            GMX_HIP(hipMemcpy(&m_f, off.p + cur_count, sizeof(int64_t), hipMemcpyDeviceToHost));
             int64_t nb = (cur_count + m_f + BFS_ITEMS - 1) / BFS_ITEMS;
             if (nb > 0)
                 hipLaunchKernelGGL(bfs_topdown_kernel, dim3((unsigned) nb), dim3(BFS_THREADS), 0, 0,
