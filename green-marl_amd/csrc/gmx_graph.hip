@@ -475,6 +475,79 @@ extern "C" int gmx_graph_create_rmat(int64_t N, int64_t M, long seed, double a, 
     return GMX_OK;
 }
 
+// ------------------------------------------------------------------ symmetrise
+// keys of both orientations of every non-loop edge
+__global__ void sym_keys_kernel(const uint64_t* __restrict__ fwd, int64_t E, uint64_t* __restrict__ out) {
+    int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    const uint64_t NONE = ~0ULL;   // sorts last, removed afterwards
+    for (; e < E; e += stride) {
+        const uint64_t k = fwd[e];
+        const uint64_t u = k >> 32, v = k & 0xffffffffu;
+        out[2 * e] = (u == v) ? NONE : k;
+        out[2 * e + 1] = (u == v) ? NONE : ((v << 32) | u);
+    }
+}
+
+struct key_is_edge {
+    __device__ bool operator()(const uint64_t& k) const { return k != ~0ULL; }
+};
+
+// Undirected simple version of g: every edge in both directions, duplicates and self loops removed
+// (the measurement preparation of the triangle-counting config).
+extern "C" int gmx_graph_symmetrize(const gmx_graph_t* g, gmx_graph_t** out) {
+    GMX_REQUIRE(g && out, "NULL argument");
+    *out = nullptr;
+    GMX_REQUIRE(2 * g->E < (1LL << 31), "symmetrised edge count exceeds int32 edge_t");
+    const int64_t E = g->E, V = g->V;
+    gmx_graph* h = new gmx_graph();
+    h->V = V;
+    (void) hipGetDevice(&h->device);
+    int st = GMX_OK;
+    do {
+        dbuf<uint64_t> fwd, both, alt, uniq;
+        dbuf<int64_t> count;
+        if ((st = fwd.alloc((size_t) E)) || (st = both.alloc((size_t) 2 * E)) || (st = alt.alloc((size_t) 2 * E)) ||
+            (st = uniq.alloc((size_t) 2 * E)) || (st = count.alloc(1))) break;
+        if ((st = gmx_keys_from_csr(g->begin.p, g->node_idx.p, V, E, false, nullptr, fwd.p, 0))) break;
+        if (E) hipLaunchKernelGGL(sym_keys_kernel, dim3(grid_for(E)), dim3(256), 0, 0, (const uint64_t*) fwd.p, E, both.p);
+        fwd.release();
+        int64_t n = 0;
+        if (E) {
+            rocprim::double_buffer<uint64_t> db(both.p, alt.p);
+            size_t tb = 0;
+            hipError_t he = rocprim::radix_sort_keys(nullptr, tb, db, (size_t) (2 * E), 0u, 64u, 0);
+            dbuf<char> tmp;
+            if (he == hipSuccess && (st = tmp.alloc(tb))) break;
+            if (he == hipSuccess) he = rocprim::radix_sort_keys((void*) tmp.p, tb, db, (size_t) (2 * E), 0u, 64u, 0);
+            size_t ub = 0;
+            if (he == hipSuccess) he = rocprim::unique(nullptr, ub, db.current(), uniq.p, count.p, (size_t) (2 * E), rocprim::equal_to<uint64_t>(), 0);
+            dbuf<char> tmp2;
+            if (he == hipSuccess && (st = tmp2.alloc(ub))) break;
+            if (he == hipSuccess) he = rocprim::unique((void*) tmp2.p, ub, db.current(), uniq.p, count.p, (size_t) (2 * E), rocprim::equal_to<uint64_t>(), 0);
+            if (he == hipSuccess) he = hipMemcpy(&n, count.p, sizeof(int64_t), hipMemcpyDeviceToHost);
+            if (he != hipSuccess) { gmx_set_error("symmetrize: %s", hipGetErrorString(he)); st = GMX_ERR_HIP; break; }
+            // the sentinel (self loops), if present, is the last unique key
+            uint64_t last = 0;
+            if (n > 0 && hipMemcpy(&last, uniq.p + (n - 1), sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) { gmx_set_error("symmetrize: copy failed"); st = GMX_ERR_HIP; break; }
+            if (n > 0 && last == ~0ULL) n--;
+        }
+        h->E = n;
+        both.release();
+        // uniq holds the sorted forward keys; the graph is its own transpose
+        if ((st = h->begin.alloc((size_t) V + 1)) || (st = h->node_idx.alloc((size_t) n)) ||
+            (st = h->r_begin.alloc((size_t) V + 1)) || (st = h->r_node_idx.alloc((size_t) n))) break;
+        hipLaunchKernelGGL(csr_extract_kernel, dim3(grid_for(n > V ? n : V + 1)), dim3(256), 0, 0, (const uint64_t*) uniq.p, V, n, h->begin.p, h->node_idx.p);
+        if (hipMemcpy(h->r_begin.p, h->begin.p, sizeof(int32_t) * ((size_t) V + 1), hipMemcpyDeviceToDevice) != hipSuccess ||
+            (n && hipMemcpy(h->r_node_idx.p, h->node_idx.p, sizeof(int32_t) * (size_t) n, hipMemcpyDeviceToDevice) != hipSuccess) ||
+            hipDeviceSynchronize() != hipSuccess) { gmx_set_error("symmetrize: csr build failed"); st = GMX_ERR_HIP; break; }
+        h->has_reverse = true;
+    } while (0);
+    if (st != GMX_OK) { delete h; return st; }
+    *out = h;
+    return GMX_OK;
+}
+
 // ------------------------------------------------------------------ misc
 extern "C" int gmx_graph_free(gmx_graph_t* g) {
     delete g;

@@ -42,7 +42,7 @@ class DeviceInfo(C.Structure):
 
 EXPORTS = [
     "gmx_last_error", "gmx_device_count", "gmx_set_device", "gmx_device_info",
-    "gmx_graph_upload", "gmx_graph_from_edges", "gmx_graph_create_rmat", "gmx_graph_free",
+    "gmx_graph_upload", "gmx_graph_from_edges", "gmx_graph_create_rmat", "gmx_graph_free", "gmx_graph_symmetrize",
     "gmx_graph_num_nodes", "gmx_graph_num_edges", "gmx_graph_download",
     "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_triangle_counting",
     "gmx_pr_create", "gmx_pr_free", "gmx_pr_reset", "gmx_pr_step", "gmx_pr_contrib_slice",
@@ -70,6 +70,7 @@ def lib():
         L.gmx_graph_create_rmat.argtypes = [i64, i64, C.c_long, C.c_double, C.c_double, C.c_double, C.c_int,
                                             C.c_uint32, C.POINTER(vp)]
         L.gmx_graph_free.argtypes = [vp]
+        L.gmx_graph_symmetrize.argtypes = [vp, C.POINTER(vp)]
         L.gmx_graph_num_nodes.argtypes = [vp]
         L.gmx_graph_num_nodes.restype = i64
         L.gmx_graph_num_edges.argtypes = [vp]
@@ -168,6 +169,12 @@ class Graph:
         h = C.c_void_p()
         _ck(lib().gmx_graph_create_rmat(N, M, seed, a, b, c, int(permute), flags, C.byref(h)))
         return cls(h)
+
+    def symmetrize(self):
+        """Undirected simple version (both orientations, duplicates and self loops dropped)."""
+        h = C.c_void_p()
+        _ck(lib().gmx_graph_symmetrize(self._h, C.byref(h)))
+        return Graph(h)
 
     # -- accessors ---------------------------------------------------------
     @property

@@ -85,6 +85,9 @@ int gmx_graph_from_edges(const gmx_node_t* src, const gmx_node_t* dst,
 int gmx_graph_create_rmat(int64_t N, int64_t M, long seed, double a, double b, double c,
                           int permute, uint32_t flags, gmx_graph_t** out);
 
+/* Undirected simple version of g (both orientations, no duplicates, no self loops); the result is
+ * its own transpose.  Measurement preparation of the triangle-counting config. */
+int gmx_graph_symmetrize(const gmx_graph_t* g, gmx_graph_t** out);
 int gmx_graph_free(gmx_graph_t* g);
 int64_t gmx_graph_num_nodes(const gmx_graph_t* g);
 int64_t gmx_graph_num_edges(const gmx_graph_t* g);
