@@ -104,6 +104,7 @@ class gm_graph
 
   private:
     void release_csr();
+    bool build_reverse_on_device();   // load_binary: reverse CSR via the GPU, false -> caller uses the host path
     void sort_rows(edge_t* row_begin, node_t* dest, edge_t* aux, edge_t* aux2);
 
     node_t _numNodes;

@@ -112,6 +112,12 @@ def test_driver_rmat_input(host_built, golden):
 
 
 @pytest.mark.gpu
+def test_gm_graph_api_with_device(host_built, golden, tmp_path):
+    """Same API check on a box with a GPU: load_binary then builds the reverse CSR on the device."""
+    test_gm_graph_api(host_built, golden, tmp_path)
+
+
+@pytest.mark.gpu
 def test_gmx_bench_tool(host_built):
     r = subprocess.run([os.path.join(PKG, "bin", "gmx_bench")], stdout=subprocess.PIPE, text=True)
     assert r.returncode == 0 and "gfx950" in r.stdout
