@@ -7,16 +7,19 @@
 // Device formulation (same arithmetic per term, fp64 row sums):
 //   * contrib[w] = rank[w] / (double) outdeg(w) is produced once per vertex by the row that
 //     owns w (the reference recomputes the same quotient once per edge);
-//   * rows are processed by a MERGE-PATH decomposition of (row ends, edges): every
-//     workgroup gets exactly ITEMS path items, so hubs and empty rows cost the same;
-//   * a workgroup streams its slice of r_node_idx with coalesced non-temporal loads, gathers
-//     contrib[] into LDS, reduces each row from LDS (thread per short row, wave per long
-//     row, __shfl_down), and applies the rank update in place;
-//   * rows that span workgroups leave fp64 partials that a small fix-up kernel adds in edge
-//     order, so the result is run-to-run deterministic (no float atomics anywhere);
 //   * vertices are internally renumbered by descending out-degree (the gather frequency of
 //     contrib[w] IS outdeg(w)), which packs the hot part of the vector into few cache lines;
-//     the hottest entries can additionally be served from LDS (GMX_PR_HOT_LDS).
+//   * work is cut by a MERGE-PATH decomposition of (row ends, edges) into blocks of PRW_ITEMS
+//     path items, so hubs and empty rows cost the same;
+//   * every WAVE is an independent worker over such blocks (no workgroup barrier in the loop): it
+//     streams its slice of r_node_idx with coalesced non-temporal loads, gathers contrib[] (from an
+//     LDS tile for the hottest ids, else from L2/HBM), stages the values in its private LDS slice,
+//     and every lane walks PRW_PER consecutive path items; rows spanning lanes are closed by a
+//     segmented wave scan, rows spanning blocks by fp64 partials that a small fix-up kernel adds in
+//     edge order -- no float atomics anywhere, results are run-to-run deterministic;
+//   * for graphs whose contribution vector outgrows the caches (GMX_PR_SLICED) the in-edges are split
+//     by SOURCE slice, one slice per group of XCDs, so each private L2 (and each CU's LDS tile)
+//     only ever serves 1/ns of the vector; per-slice row sums are added by pr_combine_kernel.
 // Roofline: HBM-bound; algorithmic bytes per iteration E*(4+s) + V*(8+3s).
 #pragma clang fp contract(off)
 
@@ -25,14 +28,11 @@
 #include <math.h>
 #include <rocprim/rocprim.hpp>
 
-#define PR_LONG 96   // rows with more in-block edges than this are reduced by a whole wave
-
 struct pr_blk { int32_t r, e; };  // merge-path start of a workgroup: local row index, local edge index
 
 #define PR_MAX_SLICES 8
 #define PR_COMBINE_GRID 4096
 #define PR_QUEUE_STRIDE 64       // work-queue counters live 256 bytes apart (one atomic unit each)
-#define PR_QUEUE_CHUNK 4         // merge-path blocks (2048 items) claimed per dequeue by a workgroup
 #define PRW_QUEUE_CHUNK 16       // merge-path blocks (512 items) claimed per dequeue by a wave
 #define PR_RUN_SHIFT 11         // sliced numbering: a slice owns runs of 2^11 consecutive ids (all L2 channels)
 
@@ -79,11 +79,8 @@ struct gmx_pr {
     dbuf<char> contrib[2];  // replicas [Vpad] x elem
     int cur = 0;          // contrib[cur] is read by the next step
     int64_t nblk = 0;
-    int items = 0, threads = 0;
+    int items = 0;
     bool hot = false;
-    bool wave = false;   // wave-worker kernels
-    int n_main = 0;      // per-wave |val-rank| partials of the last wave-kernel launch
-    int64_t n_fix_blocks = 0;
     int persistent_grid = 0;
     dbuf<pr_blk> blk;     // [nblk+1]
     dbuf<double> part_first, part_last;   // [nblk] partial row sums leaving a workgroup
@@ -315,103 +312,6 @@ struct out_partial {
     __device__ __forceinline__ void row(int64_t r, double sum, double&) const { partial[rowid[r]] = (S) sum; }
 };
 
-template <typename S, int ITEMS>
-struct pr_smem {
-    S val[ITEMS];
-    int32_t rb[ITEMS + 2];
-    int32_t longrows[ITEMS / PR_LONG + 2];
-    int32_t nlong;
-};
-
-// One merge-path block: ITEMS path items starting at blk[k].  HOT > 0: contributions of the
-// HOT hottest vertices (internal ids 0..HOT-1) are read from s_hot (LDS).  NT: non-temporal
-// loads for the index stream.  Returns this thread's |val-rank| partial through diff_acc.
-template <typename S, int THREADS, int ITEMS, int HOT, bool NT, typename OUT, int ABL = 0>
-__device__ __forceinline__ void pr_block_body(pr_smem<S, ITEMS>& sm, const S* s_hot,
-                                              const pr_blk* __restrict__ blk, int64_t k, int64_t rows,
-                                              const int32_t* __restrict__ rb, const int32_t* __restrict__ ridx,
-                                              const S* __restrict__ contrib, const OUT& out, double& diff_acc) {
-    constexpr int PER = ITEMS / THREADS;
-    constexpr int NW = THREADS / 64;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const pr_blk b0 = blk[k], b1 = blk[k + 1];
-    const int r0 = b0.r, e0 = b0.e, r1 = b1.r, e1 = b1.e;
-    const int ne = e1 - e0;
-    const int nr = r1 - r0 + 1;  // rows touched; the last one (r1) does not finish here
-
-    __syncthreads();  // previous pass done with LDS (and s_hot visible)
-    if (tid == 0) sm.nlong = 0;
-    for (int i = tid; i < nr; i += THREADS) sm.rb[i] = __builtin_nontemporal_load(rb + r0 + i);   // r1 <= rows, rb has rows+1 entries
-
-    // ---- gather: coalesced index stream, random contribution reads, staged in LDS ----
-    {
-        int32_t ix[PER];
-        S vv[PER];
-#pragma unroll
-        for (int u = 0; u < PER; u++) {
-            int j = tid + u * THREADS;
-            ix[u] = -1;
-            if (j < ne) ix[u] = NT ? __builtin_nontemporal_load(ridx + e0 + j) : ridx[e0 + j];
-        }
-#pragma unroll
-        for (int u = 0; u < PER; u++) {
-            vv[u] = (S) 0;
-            if (ix[u] >= 0) {
-                if (ABL == 1) vv[u] = (S) 1;                        // ablation: no gather
-                else if (ABL == 2) vv[u] = contrib[ix[u] & 1023];     // ablation: L1-resident gather
-                else if (HOT > 0 && ix[u] < HOT) vv[u] = s_hot[ix[u]];
-                else vv[u] = contrib[ix[u]];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < PER; u++) {
-            int j = tid + u * THREADS;
-            if (j < ne) sm.val[j] = vv[u];
-        }
-    }
-    __syncthreads();
-
-    const bool first_started_here = (sm.rb[0] >= e0);   // rb[r0] == e0
-    // ---- short rows: one thread per row, sequential fp64 sum in edge order ----
-    for (int i = tid; i < nr; i += THREADS) {
-        int lo = sm.rb[i] - e0;
-        if (lo < 0) lo = 0;
-        int hi = (i < nr - 1) ? sm.rb[i + 1] - e0 : ne;
-        if (hi - lo > PR_LONG) {
-            int q = atomicAdd(&sm.nlong, 1);
-            sm.longrows[q] = i;
-            continue;
-        }
-        double sum = 0.0;
-        for (int j = lo; j < hi; j++) sum += (double) sm.val[j];
-        const bool started = (i > 0) || first_started_here;
-        const bool finished = (i < nr - 1);
-        if (!started) out.part_first[k] = sum;
-        else if (finished) out.row((int64_t) r0 + i, sum, diff_acc);
-        else if (r0 + i < rows && hi > lo) out.part_last[k] = sum;
-    }
-    __syncthreads();
-    // ---- long rows: one wave per row, strided fp64 partials + shuffle reduction ----
-    const int nlong = sm.nlong;
-    for (int q = wave; q < nlong; q += NW) {
-        const int i = sm.longrows[q];
-        int lo = sm.rb[i] - e0;
-        if (lo < 0) lo = 0;
-        const int hi = (i < nr - 1) ? sm.rb[i + 1] - e0 : ne;
-        double sum = 0.0;
-        for (int j = lo + lane; j < hi; j += 64) sum += (double) sm.val[j];
-        sum = wave_sum(sum);
-        if (lane == 0) {
-            const bool started = (i > 0) || first_started_here;
-            const bool finished = (i < nr - 1);
-            if (!started) out.part_first[k] = sum;
-            else if (finished) out.row((int64_t) r0 + i, sum, diff_acc);
-            else if (r0 + i < rows) out.part_last[k] = sum;
-        }
-    }
-}
-
 template <int THREADS>
 __device__ __forceinline__ void pr_block_diff(double diff_acc, double* s_red, double* __restrict__ dst) {
     constexpr int NW = THREADS / 64;
@@ -427,85 +327,14 @@ __device__ __forceinline__ void pr_block_diff(double diff_acc, double* s_red, do
     }
 }
 
-// Plain variant: block k of the grid (or a persistent walk when HOT > 0) updates ranks in place.
-template <typename S, int THREADS, int ITEMS, int HOT, bool NT, int ABL = 0>
-__global__ void __launch_bounds__(THREADS)
-pr_step_kernel(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
-               const int32_t* __restrict__ rb, const int32_t* __restrict__ ridx,
-               const int32_t* __restrict__ outdeg, S* __restrict__ rk,
-               const S* __restrict__ contrib, S* __restrict__ contrib_next_owned,
-               double base, double d,
-               double* __restrict__ part_first, double* __restrict__ part_last, double* __restrict__ diff_part,
-               int64_t ncontrib) {
-    __shared__ pr_smem<S, ITEMS> sm;
-    __shared__ double s_red[THREADS / 64];
-    __shared__ S s_hot[HOT > 0 ? HOT : 1];
-    if (HOT > 0) {
-        for (int i = threadIdx.x; i < HOT; i += THREADS) s_hot[i] = i < ncontrib ? contrib[i] : (S) 0;
-    }
-    out_final<S> out{rk, outdeg, contrib_next_owned, base, d, part_first, part_last};
-    for (int64_t k = blockIdx.x; k < nblk; k += gridDim.x) {
-        double diff_acc = 0.0;
-        pr_block_body<S, THREADS, ITEMS, HOT, NT, out_final<S>, ABL>(sm, s_hot, blk, k, rows, rb, ridx, contrib, out, diff_acc);
-        pr_block_diff<THREADS>(diff_acc, s_red, diff_part + k);
-    }
-}
-
 __device__ __forceinline__ int pr_xcc_id() {
     unsigned v;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
     return (int) (v & 0xf);
 }
 
-// XCD-sliced variant: persistent workgroups; a workgroup on XCD x claims merge-path blocks of
-// slice x % ns from a queue (and steals from the other slices once its own is drained, which
-// only costs locality).  Row sums go to partial[slice][row]; pr_combine_kernel adds the slices.
-template <typename S, int THREADS, int ITEMS, bool NT, int ABL = 0>
-__global__ void __launch_bounds__(THREADS)
-pr_sliced_kernel(pr_sliced_args a, int64_t rows, const S* __restrict__ contrib) {
-    __shared__ pr_smem<S, ITEMS> sm;
-    __shared__ long long s_k;
-    __shared__ int s_sl;
-    const int home = pr_xcc_id() % a.ns;
-    // thread 0 owns the dequeue state: a claimed chunk [k_next, k_end) of slice `cur`
-    long long k_next = 0, k_end = 0;
-    int cur = home, first_try = 0;   // slices before offset first_try (from home) are drained
-    for (;;) {
-        if (threadIdx.x == 0) {
-            long long k = -1;
-            if (k_next < k_end) k = k_next++;
-            else {
-                for (int t = first_try; t < a.ns; t++) {
-                    cur = (home + t) % a.ns;
-                    const long long nb = a.s[cur].nblk;
-                    long long kk = (long long) atomicAdd(&a.queue[cur * PR_QUEUE_STRIDE], (unsigned int) PR_QUEUE_CHUNK);
-                    if (kk < nb) {
-                        k = kk;
-                        k_next = kk + 1;
-                        k_end = kk + PR_QUEUE_CHUNK < nb ? kk + PR_QUEUE_CHUNK : nb;
-                        first_try = t;
-                        break;
-                    }
-                    first_try = t + 1;
-                }
-            }
-            s_k = k;
-            s_sl = cur;
-        }
-        __syncthreads();
-        const long long k = s_k;
-        const int sl = s_sl;
-        if (k < 0) break;
-        const pr_slice_desc& sd = a.s[sl];
-        out_partial<S> out{(S*) sd.partial, sd.rowid, sd.part_first, sd.part_last};
-        double diff_acc = 0.0;
-        pr_block_body<S, THREADS, ITEMS, 0, NT, out_partial<S>, ABL>(sm, (const S*) nullptr, sd.blk, (int64_t) k, sd.crows, sd.rb, sd.ridx, contrib, out, diff_acc);
-        __syncthreads();   // s_k / s_sl are rewritten by thread 0 at the top
-    }
-}
-
 // ======================================================================================
-// Wave-worker formulation (GMX_PR_WAVE): every WAVE is an independent worker that walks
+// Wave-worker formulation: every WAVE is an independent worker that walks
 // merge-path blocks of PRW_ITEMS items; there is no workgroup barrier in the loop, the row
 // starts / outdeg / old rank of a block live in registers, the next block's index slice is
 // prefetched while the current block is reduced, and the per-wave |val-rank| partial stays in a
@@ -514,11 +343,11 @@ pr_sliced_kernel(pr_sliced_args a, int64_t rows, const S* __restrict__ contrib) 
 #define PRW_ITEMS 512
 #define PRW_PER (PRW_ITEMS / 64)
 #define PRW_ROWU ((PRW_ITEMS + 1 + 63) / 64)
-#define PRW_LONG 32
 
+#define PRW_PAD(j) ((j) + ((j) >> 5))   // one pad word per 32: stride-8 lane accesses hit 32 different banks
 template <typename S>
 struct prw_lds {
-    S val[PRW_ITEMS];
+    S val[PRW_ITEMS + PRW_ITEMS / 32 + 2];
     int32_t rb[PRW_ITEMS + 2];
 };
 
@@ -536,6 +365,7 @@ struct prw_final {
     double* part_first;
     double* part_last;
     static constexpr bool needs_vertex_data = true;
+    __device__ __forceinline__ int32_t preload(int64_t) const { return 0; }
     __device__ __forceinline__ void row(int64_t r, double sum, int32_t od, S old, double& diff_acc) const {
         if (od < 0) return;   // padding row
         double val = base + d * sum;
@@ -552,28 +382,33 @@ struct prw_partial {
     double* part_first;
     double* part_last;
     static constexpr bool needs_vertex_data = false;
-    __device__ __forceinline__ void row(int64_t r, double sum, int32_t, S, double&) const {
-        partial[__builtin_nontemporal_load(rowid + r)] = (S) sum;
-    }
+    // `rid` = rowid[r], preloaded with the row starts (no dependent load inside the reduction loop)
+    __device__ __forceinline__ void row(int64_t, double sum, int32_t rid, S, double&) const { partial[rid] = (S) sum; }
+    __device__ __forceinline__ int32_t preload(int64_t r) const { return __builtin_nontemporal_load(rowid + r); }
 };
 
-// Consume one block whose index slice is already in ix[] (prefetched); prefetch the next block's
+// Consume one block whose index slice is already in ix[] (prefetched) and prefetch the next block's
 // slice (ridx_n + e0n, nen entries) into ixn[] behind the gathers.  hot_lim == 0 disables the tile.
-template <typename S, bool NT, typename OUT, int ABL>
+// Row reduction: every lane walks exactly PRW_PER consecutive items of the block's merge path (edges
+// and row ends), so there is no divergence and no per-row loop; rows that span lanes are closed by a
+// wave-wide segmented scan of the lanes' open sums.  A finished row's sum is parked in the LDS slot of
+// the row's last edge (already consumed, hence free) and written out one lane per row, coalesced.
+template <typename S, bool NT, typename OUT>
 __device__ __forceinline__ void prw_block(prw_lds<S>* __restrict__ w, const S* __restrict__ s_hot, int hot_lim,
-                                          int hot_shift, int hot_sl_shift,
-                                          int64_t k, pr_blk b0, pr_blk b1, int64_t rows,
-                                          const int32_t* __restrict__ rb, const int32_t* __restrict__ outdeg,
-                                          const S* __restrict__ rk_old, const S* __restrict__ contrib,
-                                          const int32_t (&ix)[PRW_PER],
-                                          const int32_t* __restrict__ ridx_n, int e0n, int nen, int32_t (&ixn)[PRW_PER],
-                                          const OUT& out, double& diff_acc) {
+                                              int hot_shift, int hot_sl_shift,
+                                              int64_t k, pr_blk b0, pr_blk b1, int64_t rows,
+                                              const int32_t* __restrict__ rb, const int32_t* __restrict__ outdeg,
+                                              const S* __restrict__ rk_old, const S* __restrict__ contrib,
+                                              const int32_t (&ix)[PRW_PER],
+                                              const int32_t* __restrict__ ridx_n, int e0n, int nen, int32_t (&ixn)[PRW_PER],
+                                              const OUT& out, double& diff_acc) {
     const int lane = threadIdx.x & 63;
     const int r0 = b0.r, e0 = b0.e, r1 = b1.r, e1 = b1.e;
     const int ne = e1 - e0;
     const int nr = r1 - r0 + 1;
+    const int nends = nr - 1;          // row-end items of this block
+    const int total = nends + ne;      // path items of this block
 
-    // ---- issue: row starts (+ outdeg / old rank of the rows this block can finish) ----
     int32_t rbv[PRW_ROWU], od[PRW_ROWU];
     S old[PRW_ROWU];
 #pragma unroll
@@ -584,37 +419,33 @@ __device__ __forceinline__ void prw_block(prw_lds<S>* __restrict__ w, const S* _
         old[u] = (S) 0;
         if (i < nr) {
             rbv[u] = __builtin_nontemporal_load(rb + r0 + i);
-            if (OUT::needs_vertex_data && i < nr - 1) {
-                od[u] = __builtin_nontemporal_load(outdeg + r0 + i);
-                old[u] = __builtin_nontemporal_load(rk_old + r0 + i);
+            if (i < nr - 1) {
+                if (OUT::needs_vertex_data) {
+                    od[u] = __builtin_nontemporal_load(outdeg + r0 + i);
+                    old[u] = __builtin_nontemporal_load(rk_old + r0 + i);
+                } else od[u] = out.preload((int64_t) r0 + i);
             }
         }
     }
-    // ---- issue: gathers ----
     S vv[PRW_PER];
 #pragma unroll
     for (int u = 0; u < PRW_PER; u++) {
         vv[u] = (S) 0;
         const int32_t id = ix[u];
         if (id >= 0) {
-            if (ABL == 1) vv[u] = (S) 1;
-            else if (ABL == 2) vv[u] = contrib[id & 1023];
-            else {
-                // tile slot of an id of the home slice: drop the slice bits above the run offset
-                const int q = ((id >> (PR_RUN_SHIFT + hot_sl_shift)) << PR_RUN_SHIFT) | (id & ((1 << PR_RUN_SHIFT) - 1));
-                if (hot_lim > 0 && (hot_shift ? q : id) < hot_lim) vv[u] = s_hot[hot_shift ? q : id];
-                else vv[u] = contrib[id];
-            }
+            // tile slot of an id of the home slice: drop the slice bits above the run offset
+            const int q = ((id >> (PR_RUN_SHIFT + hot_sl_shift)) << PR_RUN_SHIFT) | (id & ((1 << PR_RUN_SHIFT) - 1));
+            const int slot = hot_shift ? q : id;
+            if (slot < hot_lim) vv[u] = s_hot[slot];
+            else vv[u] = contrib[id];
         }
     }
-    // ---- prefetch the next block's index slice ----
 #pragma unroll
     for (int u = 0; u < PRW_PER; u++) {
         const int j = lane + 64 * u;
         ixn[u] = -1;
         if (j < nen) ixn[u] = NT ? __builtin_nontemporal_load(ridx_n + e0n + j) : ridx_n[e0n + j];
     }
-    // ---- stage in this wave's LDS ----
 #pragma unroll
     for (int u = 0; u < PRW_ROWU; u++) {
         const int i = lane + 64 * u;
@@ -623,51 +454,98 @@ __device__ __forceinline__ void prw_block(prw_lds<S>* __restrict__ w, const S* _
 #pragma unroll
     for (int u = 0; u < PRW_PER; u++) {
         const int j = lane + 64 * u;
-        if (j < ne) w->val[j] = vv[u];
+        if (j < ne) w->val[PRW_PAD(j)] = vv[u];
     }
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible to all its lanes
+    __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
 
     const bool first_started_here = (w->rb[0] >= e0);
+    // ---- this lane's start on the merge path: i row ends and j edges consumed before item d0 ----
+    const int d0 = lane * PRW_PER;
+    const bool active = d0 < total;
+    int i = 0, j = 0;
+    if (active) {
+        int lo = d0 > ne ? d0 - ne : 0, hi = d0 < nends ? d0 : nends;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (w->rb[mid + 1] - e0 <= d0 - mid - 1) lo = mid + 1; else hi = mid;
+        }
+        i = lo;
+        j = d0 - lo;
+    }
+    double acc = 0.0, head = 0.0;
+    int first_end = -1;
+    int row_start = j;                                  // first in-lane edge of the row being summed
+    int cur_end = (active && i < nends) ? w->rb[i + 1] - e0 : 0x7fffffff;
+#pragma unroll
+    for (int sidx = 0; sidx < PRW_PER; sidx++) {
+        if (active && d0 + sidx < total) {
+            if (j < cur_end) {
+                acc += (double) w->val[PRW_PAD(j)];
+                j++;
+            } else {                                    // row i ends here
+                if (first_end < 0) {
+                    head = acc;
+                    first_end = i;
+                } else if (j > row_start) w->val[PRW_PAD(j - 1)] = (S) acc;   // row lies inside this lane
+                acc = 0.0;
+                i++;
+                row_start = j;
+                cur_end = (i < nends) ? w->rb[i + 1] - e0 : 0x7fffffff;
+            }
+        }
+    }
+    // ---- segmented inclusive scan over lanes of the open sums (a lane with a row end restarts the segment) ----
+    double v = acc;
+    int f = first_end >= 0 ? 1 : 0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double vo = __shfl_up(v, off, 64);
+        const int fo = __shfl_up(f, off, 64);
+        if (lane >= off) {
+            if (!f) v += vo;
+            f |= fo;
+        }
+    }
+    double carry_in = __shfl_up(v, 1, 64);
+    if (lane == 0) carry_in = 0.0;
+    const double block_tail = __shfl(v, 63, 64);       // open sum of row r1 at the end of the block
+    if (first_end >= 0) {
+        const int fe_end = w->rb[first_end + 1] - e0;
+        int fs = w->rb[first_end] - e0;
+        if (fs < 0) fs = 0;
+        if (fe_end > fs) w->val[PRW_PAD(fe_end - 1)] = (S) (head + carry_in);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- coalesced output: lane per row ----
 #pragma unroll
     for (int u = 0; u < PRW_ROWU; u++) {
         if (64 * u >= nr) break;
-        const int i = lane + 64 * u;
-        const bool valid = i < nr;
-        int lo = 0, hi = 0;
-        if (valid) {
-            lo = rbv[u] - e0;
+        const int ri = lane + 64 * u;
+        if (ri < nr) {
+            int lo = rbv[u] - e0;
             if (lo < 0) lo = 0;
-            hi = (i < nr - 1) ? w->rb[i + 1] - e0 : ne;
-        }
-        const bool is_long = valid && (hi - lo > PRW_LONG);
-        double sum = 0.0;
-        if (valid && !is_long)
-            for (int j = lo; j < hi; j++) sum += (double) w->val[j];
-        unsigned long long m = __ballot(is_long);
-        while (m) {   // long rows: the whole wave strides over the segment
-            const int l = __ffsll((long long) m) - 1;
-            m &= m - 1;
-            const int llo = __shfl(lo, l, 64), lhi = __shfl(hi, l, 64);
-            double t = 0.0;
-            for (int j = llo + lane; j < lhi; j += 64) t += (double) w->val[j];
-            t = wave_allsum(t);
-            if (lane == l) sum = t;
-        }
-        if (valid) {
-            const bool started = (i > 0) || first_started_here;
-            const bool finished = (i < nr - 1);
-            if (!started) out.part_first[k] = sum;
-            else if (finished) out.row((int64_t) r0 + i, sum, od[u], old[u], diff_acc);
-            else if (r0 + i < rows && hi > lo) out.part_last[k] = sum;
+            const bool started = (ri > 0) || first_started_here;
+            if (ri < nr - 1) {
+                const int hi = w->rb[ri + 1] - e0;
+                const double sum = hi > lo ? (double) w->val[PRW_PAD(hi - 1)] : 0.0;
+                if (!started) out.part_first[k] = sum;
+                else out.row((int64_t) r0 + ri, sum, od[u], old[u], diff_acc);
+            } else {
+                if (!started) out.part_first[k] = block_tail;
+                else if (r0 + ri < rows && ne > lo) out.part_last[k] = block_tail;
+            }
         }
     }
-    __builtin_amdgcn_wave_barrier();   // all lanes done reading before the next block overwrites the LDS slice
+    __builtin_amdgcn_wave_barrier();
 }
 
 // Unsliced: wave w of the grid handles blocks w, w + W, w + 2W, ... (static, deterministic).
-template <typename S, int WAVES, int HOT, bool NT, int ABL>
+template <typename S, int WAVES, int HOT, bool NT>
 __global__ void __launch_bounds__(WAVES * 64)
 pr_wave_kernel(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
                const int32_t* __restrict__ rb, const int32_t* __restrict__ ridx,
@@ -708,7 +586,7 @@ pr_wave_kernel(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
             n0 = blk[kn];
             n1 = blk[kn + 1];
         }
-        prw_block<S, NT, prw_final<S>, ABL>(w, s_hot, HOT, 0, 0, k, b0, b1, rows, rb, outdeg, rk, contrib, ix,
+        prw_block<S, NT, prw_final<S>>(w, s_hot, HOT, 0, 0, k, b0, b1, rows, rb, outdeg, rk, contrib, ix,
                                              ridx, n0.e, n1.e - n0.e, ixn, out, diff_acc);
         k = kn;
         b0 = n0;
@@ -721,7 +599,7 @@ pr_wave_kernel(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
 }
 
 // Sliced: waves on XCD x claim chunks of slice x % ns (stealing from the others when drained).
-template <typename S, int WAVES, int HOT, bool NT, int ABL>
+template <typename S, int WAVES, int HOT, bool NT>
 __global__ void __launch_bounds__(WAVES * 64)
 pr_wave_sliced_kernel(pr_sliced_args a, int64_t rows, const S* __restrict__ contrib, int ns_shift) {
     __shared__ prw_lds<S> lds[WAVES];
@@ -792,7 +670,7 @@ pr_wave_sliced_kernel(pr_sliced_args a, int64_t rows, const S* __restrict__ cont
         }
         const pr_slice_desc& sd = a.s[sl];
         prw_partial<S> out{(S*) sd.partial, sd.rowid, sd.part_first, sd.part_last};
-        prw_block<S, NT, prw_partial<S>, ABL>(w, s_hot, (HOT > 0 && sl == home) ? HOT : 0, 1, ns_shift, (int64_t) k, b0, b1, sd.crows,
+        prw_block<S, NT, prw_partial<S>>(w, s_hot, (HOT > 0 && sl == home) ? HOT : 0, 1, ns_shift, (int64_t) k, b0, b1, sd.crows,
                                                sd.rb, (const int32_t*) nullptr, (const S*) nullptr, contrib, ix,
                                                kn >= 0 ? a.s[sln].ridx : sd.ridx, n0.e, n1.e - n0.e, ixn, out, unused);
         k = kn;
@@ -947,11 +825,8 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
         p->rows_real = hi > p->row_lo ? hi - p->row_lo : 0;
     }
     p->rows = p->ns > 0 ? p->slice : p->rows_real;
-    p->wave = (options & GMX_PR_WAVE) != 0;
-    p->hot = (options & GMX_PR_HOT_LDS) != 0 && relabel && nranks == 1 && (p->ns == 0 || p->wave);
-    p->threads = p->hot ? 1024 : 256;
-    p->items = p->wave ? PRW_ITEMS : (p->hot ? 4096 : 2048);
-    if (!p->hot && p->ns == 0 && getenv("GMX_PR_ITEMS") && atoi(getenv("GMX_PR_ITEMS")) == 4096) p->items = 4096;   // development only
+    p->hot = (options & GMX_PR_HOT_LDS) != 0 && relabel && nranks == 1;
+    p->items = PRW_ITEMS;
 
     const int64_t V = g->V, E = g->E;
     hipStream_t s = 0;
@@ -1167,118 +1042,63 @@ extern "C" int gmx_pr_reset(gmx_pr_t* p, double d) {
     return GMX_OK;
 }
 
-template <typename S>
-static void launch_fixup(gmx_pr* p, hipStream_t s, int64_t n_main);
-
-template <typename S, int THREADS, int ITEMS, int HOT>
-static void launch_step(gmx_pr* p, hipStream_t s, int grid) {
-    const double N = (double) p->V;
-    const double base = (1 - p->d) / N;
-    S* next_owned = (S*) p->contrib[1 - p->cur].p + p->row_lo;
-    static const int abl = getenv("GMX_PR_ABLATE") ? atoi(getenv("GMX_PR_ABLATE")) : 0;   // development only
-    if (abl == 1 || abl == 2) {
-        if (abl == 1)
-            hipLaunchKernelGGL((pr_step_kernel<S, THREADS, ITEMS, HOT, true, 1>), dim3(grid), dim3(THREADS), 0, s,
-                               p->blk.p, p->nblk, p->rows, p->rb, p->ridx, p->outdeg.p, (S*) p->rk.p,
-                               (const S*) p->contrib[p->cur].p, next_owned, base, p->d,
-                               p->part_first.p, p->part_last.p, p->diff_part.p, p->Vpad);
-        else
-            hipLaunchKernelGGL((pr_step_kernel<S, THREADS, ITEMS, HOT, true, 2>), dim3(grid), dim3(THREADS), 0, s,
-                               p->blk.p, p->nblk, p->rows, p->rb, p->ridx, p->outdeg.p, (S*) p->rk.p,
-                               (const S*) p->contrib[p->cur].p, next_owned, base, p->d,
-                               p->part_first.p, p->part_last.p, p->diff_part.p, p->Vpad);
-    } else
-    hipLaunchKernelGGL((pr_step_kernel<S, THREADS, ITEMS, HOT, true>), dim3(grid), dim3(THREADS), 0, s,
-                       p->blk.p, p->nblk, p->rows, p->rb, p->ridx, p->outdeg.p, (S*) p->rk.p,
-                       (const S*) p->contrib[p->cur].p, next_owned, base, p->d,
-                       p->part_first.p, p->part_last.p, p->diff_part.p, p->Vpad);
-    launch_fixup<S>(p, s, p->nblk);
-}
-
-template <typename S>
-static void launch_fixup(gmx_pr* p, hipStream_t s, int64_t n_main) {
-    const double N = (double) p->V;
-    const double base = (1 - p->d) / N;
-    S* next_owned = (S*) p->contrib[1 - p->cur].p + p->row_lo;
-    const int64_t n = p->nblk > n_main ? p->nblk : n_main;
-    p->n_fix_blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(pr_fixup_kernel<S>, dim3((unsigned) p->n_fix_blocks), dim3(256), 0, s,
-                       p->blk.p, p->nblk, p->rows, p->rb, p->outdeg.p, (S*) p->rk.p, next_owned, base, p->d,
-                       p->part_first.p, p->part_last.p, (const double*) p->diff_part.p, n_main, p->diff_part.p + p->nblk + 4096);
-}
-
+// Unsliced step: wave kernel + fix-up of rows spanning blocks (which also folds the diff partials).
 template <typename S, int WAVES, int HOT>
 static void launch_wave(gmx_pr* p, hipStream_t s) {
     const double N = (double) p->V;
     const double base = (1 - p->d) / N;
     S* next_owned = (S*) p->contrib[1 - p->cur].p + p->row_lo;
-    static const int abl = getenv("GMX_PR_ABLATE") ? atoi(getenv("GMX_PR_ABLATE")) : 0;   // development only
-    static const int occ_env = getenv("GMX_PR_WG_PER_CU") ? atoi(getenv("GMX_PR_WG_PER_CU")) : 0;
-    int per_cu = HOT > 0 ? 1 : (occ_env > 0 ? occ_env : 5);
+    // workgroups per CU: one with the LDS tile (it fills the LDS), else what the ~90 VGPRs admit (5 waves/SIMD)
+    const int per_cu = HOT > 0 ? 1 : 5;
     int64_t grid = (int64_t) p->persistent_grid * per_cu;
     const int64_t need = (p->nblk + WAVES - 1) / WAVES;
     if (grid > need) grid = need;
-    p->n_main = (int) (grid * WAVES);
-#define GMX_LAUNCH_WAVE(A)                                                                                         \
-    hipLaunchKernelGGL((pr_wave_kernel<S, WAVES, HOT, true, A>), dim3((unsigned) grid), dim3(WAVES * 64), 0, s,    \
-                       p->blk.p, p->nblk, p->rows, p->rb, p->ridx, p->outdeg.p, (S*) p->rk.p,                     \
-                       (const S*) p->contrib[p->cur].p, next_owned, base, p->d, p->part_first.p, p->part_last.p, \
-                       p->diff_part.p, p->Vpad)
-    if (abl == 1) GMX_LAUNCH_WAVE(1);
-    else if (abl == 2) GMX_LAUNCH_WAVE(2);
-    else GMX_LAUNCH_WAVE(0);
-#undef GMX_LAUNCH_WAVE
-    launch_fixup<S>(p, s, p->n_main);
+    const int64_t n_main = grid * WAVES;   // per-wave |val-rank| partials
+    hipLaunchKernelGGL((pr_wave_kernel<S, WAVES, HOT, true>), dim3((unsigned) grid), dim3(WAVES * 64), 0, s,
+                       p->blk.p, p->nblk, p->rows, p->rb, p->ridx, p->outdeg.p, (S*) p->rk.p,
+                       (const S*) p->contrib[p->cur].p, next_owned, base, p->d, p->part_first.p, p->part_last.p,
+                       p->diff_part.p, p->Vpad);
+    const int64_t n = p->nblk > n_main ? p->nblk : n_main;
+    const int64_t fix_blocks = (n + 255) / 256;
+    double* diff_fix = p->diff_part.p + p->nblk + 4096;
+    hipLaunchKernelGGL(pr_fixup_kernel<S>, dim3((unsigned) fix_blocks), dim3(256), 0, s,
+                       p->blk.p, p->nblk, p->rows, p->rb, p->outdeg.p, (S*) p->rk.p, next_owned, base, p->d,
+                       p->part_first.p, p->part_last.p, (const double*) p->diff_part.p, n_main, diff_fix);
+    hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) diff_fix, fix_blocks, p->diff.p);
 }
 
+// Sliced step: per-slice row sums, fix-up per slice, then the combine pass that applies the update.
 template <typename S>
 static void launch_sliced(gmx_pr* p, hipStream_t s) {
     const double N = (double) p->V;
     const double base = (1 - p->d) / N;
     S* next_owned = (S*) p->contrib[1 - p->cur].p + p->row_lo;
     (void) hipMemsetAsync(p->sl_queue.p, 0, sizeof(unsigned int) * PR_MAX_SLICES * PR_QUEUE_STRIDE, s);
-    int64_t maxblk = 0;
-    for (int q = 0; q < p->ns; q++) maxblk = p->sl.s[q].nblk > maxblk ? p->sl.s[q].nblk : maxblk;
-    int64_t total_blk = 0;
-    for (int q = 0; q < p->ns; q++) total_blk += p->sl.s[q].nblk;
-    int grid = p->persistent_grid * 8;   // 8 workgroups of 256 threads per CU
-    if (grid > total_blk) grid = (int) total_blk;
-    if (grid > 0 && p->wave) {
-        static const int ablw = getenv("GMX_PR_ABLATE") ? atoi(getenv("GMX_PR_ABLATE")) : 0;   // development only
+    int64_t maxblk = 0, total_blk = 0;
+    for (int q = 0; q < p->ns; q++) {
+        maxblk = p->sl.s[q].nblk > maxblk ? p->sl.s[q].nblk : maxblk;
+        total_blk += p->sl.s[q].nblk;
+    }
+    if (total_blk > 0) {
         int ns_shift = 0;
         while ((1 << ns_shift) < p->ns) ns_shift++;
-            if (p->hot && (1 << ns_shift) == p->ns) {
+        if (p->hot && (1 << ns_shift) == p->ns) {   // the tile's slot arithmetic needs a power-of-two slice count
             constexpr int HOTQ = sizeof(S) == 4 ? 22528 : 7168;
-            int64_t g2 = p->persistent_grid;
-            if (g2 * 16 > total_blk) g2 = (total_blk + 15) / 16;
-            hipLaunchKernelGGL((pr_wave_sliced_kernel<S, 16, HOTQ, true, 0>), dim3((unsigned) g2), dim3(1024), 0, s, p->sl, p->rows,
+            int64_t grid = p->persistent_grid;
+            if (grid * 16 > total_blk) grid = (total_blk + 15) / 16;
+            hipLaunchKernelGGL((pr_wave_sliced_kernel<S, 16, HOTQ, true>), dim3((unsigned) grid), dim3(1024), 0, s, p->sl, p->rows,
                                (const S*) p->contrib[p->cur].p, ns_shift);
         } else {
-            int64_t g2 = (int64_t) p->persistent_grid * 8;
-            if (g2 * 4 > total_blk) g2 = (total_blk + 3) / 4;
-            if (ablw == 1)
-                hipLaunchKernelGGL((pr_wave_sliced_kernel<S, 4, 0, true, 1>), dim3((unsigned) g2), dim3(256), 0, s, p->sl, p->rows,
-                                   (const S*) p->contrib[p->cur].p, ns_shift);
-            else
-                hipLaunchKernelGGL((pr_wave_sliced_kernel<S, 4, 0, true, 0>), dim3((unsigned) g2), dim3(256), 0, s, p->sl, p->rows,
-                                   (const S*) p->contrib[p->cur].p, ns_shift);
+            int64_t grid = (int64_t) p->persistent_grid * 5;
+            if (grid * 4 > total_blk) grid = (total_blk + 3) / 4;
+            hipLaunchKernelGGL((pr_wave_sliced_kernel<S, 4, 0, true>), dim3((unsigned) grid), dim3(256), 0, s, p->sl, p->rows,
+                               (const S*) p->contrib[p->cur].p, ns_shift);
         }
-            hipLaunchKernelGGL(pr_sliced_fixup_kernel<S>, dim3((unsigned) ((maxblk + 255) / 256), p->ns), dim3(256), 0, s, p->sl, p->rows);
-    } else if (grid > 0) {
-            static const int abl = getenv("GMX_PR_ABLATE") ? atoi(getenv("GMX_PR_ABLATE")) : 0;   // development only
-        if (abl == 1)
-            hipLaunchKernelGGL((pr_sliced_kernel<S, 256, 2048, true, 1>), dim3(grid), dim3(256), 0, s, p->sl, p->rows,
-                               (const S*) p->contrib[p->cur].p);
-        else if (abl == 2)
-            hipLaunchKernelGGL((pr_sliced_kernel<S, 256, 2048, true, 2>), dim3(grid), dim3(256), 0, s, p->sl, p->rows,
-                               (const S*) p->contrib[p->cur].p);
-        else
-        hipLaunchKernelGGL((pr_sliced_kernel<S, 256, 2048, true>), dim3(grid), dim3(256), 0, s, p->sl, p->rows,
-                           (const S*) p->contrib[p->cur].p);
-            hipLaunchKernelGGL(pr_sliced_fixup_kernel<S>, dim3((unsigned) ((maxblk + 255) / 256), p->ns), dim3(256), 0, s, p->sl, p->rows);
+        hipLaunchKernelGGL(pr_sliced_fixup_kernel<S>, dim3((unsigned) ((maxblk + 255) / 256), p->ns), dim3(256), 0, s, p->sl, p->rows);
     }
     hipLaunchKernelGGL(pr_combine_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, p->sl, p->rows, p->outdeg.p, (S*) p->rk.p,
                        next_owned, base, p->d, p->diff_part.p);
+    hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) p->diff_part.p, (int64_t) PR_COMBINE_GRID, p->diff.p);
 }
 
 extern "C" int gmx_pr_step(gmx_pr_t* p, void* stream) {
@@ -1289,9 +1109,8 @@ extern "C" int gmx_pr_step(gmx_pr_t* p, void* stream) {
         if (p->rows > 0) {
             if (p->elem == 4) launch_sliced<float>(p, s);
             else launch_sliced<double>(p, s);
-            hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) p->diff_part.p, (int64_t) PR_COMBINE_GRID, p->diff.p);
         }
-    } else if (p->nblk > 0 && p->wave) {
+    } else if (p->nblk > 0) {
         if (p->hot) {
             if (p->elem == 4) launch_wave<float, 16, 22528>(p, s);
             else launch_wave<double, 16, 7168>(p, s);
@@ -1299,21 +1118,6 @@ extern "C" int gmx_pr_step(gmx_pr_t* p, void* stream) {
             if (p->elem == 4) launch_wave<float, 4, 0>(p, s);
             else launch_wave<double, 4, 0>(p, s);
         }
-        hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) (p->diff_part.p + p->nblk + 4096), p->n_fix_blocks, p->diff.p);
-    } else if (p->nblk > 0) {
-        if (p->hot) {
-            int grid = p->persistent_grid < p->nblk ? p->persistent_grid : (int) p->nblk;
-            if (p->elem == 4) launch_step<float, 1024, 4096, 28672>(p, s, grid);
-            else launch_step<double, 1024, 4096, 12288>(p, s, grid);
-        } else {
-            GMX_REQUIRE(p->nblk < (1LL << 31), "too many workgroups");
-            if (p->items == 4096) {
-                if (p->elem == 4) launch_step<float, 256, 4096, 0>(p, s, (int) p->nblk);
-                else launch_step<double, 256, 4096, 0>(p, s, (int) p->nblk);
-            } else if (p->elem == 4) launch_step<float, 256, 2048, 0>(p, s, (int) p->nblk);
-            else launch_step<double, 256, 2048, 0>(p, s, (int) p->nblk);
-        }
-        hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) (p->diff_part.p + p->nblk + 4096), p->n_fix_blocks, p->diff.p);
     }
     pr_ev_end(p, s);
     GMX_HIP(hipGetLastError());
@@ -1370,7 +1174,7 @@ extern "C" int gmx_pr_download(gmx_pr_t* p, void* rank_host) {
 // vector mostly lives in L2 / Infinity Cache and the unsliced wave kernel with an LDS hot tile wins;
 // above, splitting the sources over the XCD L2s pays for its partial-sum pass.
 extern "C" uint32_t gmx_pr_default_options(int64_t V, int nranks) {
-    uint32_t o = GMX_PR_RELABEL | GMX_PR_WAVE;
+    uint32_t o = GMX_PR_RELABEL;
     if (nranks == 1) o |= GMX_PR_HOT_LDS;
     if (V > (1LL << 25)) o |= GMX_PR_SLICED;
     return o;
@@ -1399,10 +1203,8 @@ extern "C" int gmx_pr_kernel_time(gmx_pr_t* p, int32_t* launches, double* mean_m
 
 extern "C" const char* gmx_pr_kernel_name(gmx_pr_t* p) {
     if (!p) return "";
-    if (p->ns > 0)
-        return p->wave ? "pr_wave_sliced_kernel+pr_sliced_fixup_kernel+pr_combine_kernel+pr_diff_reduce_kernel"
-                       : "pr_sliced_kernel+pr_sliced_fixup_kernel+pr_combine_kernel+pr_diff_reduce_kernel";
-    return p->wave ? "pr_wave_kernel+pr_fixup_kernel+pr_diff_reduce_kernel" : "pr_step_kernel+pr_fixup_kernel+pr_diff_reduce_kernel";
+    if (p->ns > 0) return "pr_wave_sliced_kernel+pr_sliced_fixup_kernel+pr_combine_kernel+pr_diff_reduce_kernel";
+    return "pr_wave_kernel+pr_fixup_kernel+pr_diff_reduce_kernel";
 }
 
 extern "C" int gmx_pr_work(gmx_pr_t* p, int64_t* edges, int64_t* rows, int64_t* algorithmic_bytes) {

@@ -17,7 +17,6 @@ GMX_GRAPH_NO_REVERSE = 0x2
 GMX_PR_RELABEL = 0x1
 GMX_PR_HOT_LDS = 0x2
 GMX_PR_SLICED = 0x4
-GMX_PR_WAVE = 0x8
 INT_MAX = 2147483647
 
 

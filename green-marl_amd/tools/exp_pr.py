@@ -15,7 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scales", default="20,22,24")
     ap.add_argument("--permute", default="0,1")
-    ap.add_argument("--opts", default="0,1,3")
+    ap.add_argument("--opts", default="0,1,3,5,7")
     ap.add_argument("--elems", default="4")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--bfs", type=int, default=1)

@@ -135,7 +135,6 @@ int gmx_triangle_counting(gmx_graph_t* g, int64_t* count, gmx_stats_t* stats);
 /* options bit flags */
 #define GMX_PR_RELABEL   0x1u   /* degree-sorted internal numbering (default on in whole-kernel entries) */
 #define GMX_PR_HOT_LDS   0x2u   /* keep the hottest contributions in LDS */
-#define GMX_PR_WAVE      0x8u   /* wave-worker kernels (no workgroup barriers, register-resident row data, prefetch) */
 #define GMX_PR_SLICED    0x4u   /* split in-edges by source slice, one slice per XCD L2 (needs GMX_PR_RELABEL) */
 /* The option set the whole-kernel entries use for a graph of V vertices on nranks ranks. */
 uint32_t gmx_pr_default_options(int64_t V, int nranks);
