@@ -59,6 +59,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
+    # Keep stdout clean for the ONE JSON line: libraries (RCCL prints a version banner to stdout) are
+    # pointed at stderr for the whole run, the result goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -75,7 +81,9 @@ def main():
     gmx.require_device()                       # no CPU fallback: fail loudly without the HIP path
     torch.cuda.set_device(local_rank)
     gmx.set_device(local_rank)
-    if world > 1:
+    # GMX_BENCH_FORCE_COLLECTIVES=1 (development): run the RCCL calls with a single rank too
+    force_coll = os.environ.get("GMX_BENCH_FORCE_COLLECTIVES") == "1" and "MASTER_PORT" in os.environ
+    if world > 1 or force_coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -90,7 +98,7 @@ def main():
     t0 = time.perf_counter()
     graph = gmx.Graph.rmat(N, M, 1997, 0.57, 0.19, 0.19, True)
     engine = GmxEngine(gmx, graph, elem, rank, world, options)
-    pr = DistPageRank(engine)
+    pr = DistPageRank(engine, always_exchange=force_coll)
     pr.reset(0.85)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
@@ -139,8 +147,9 @@ def main():
                          "algorithmic_bytes_per_launch": work["algorithmic_bytes"]},
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if world > 1 or force_coll:
         dist.destroy_process_group()
 
 

@@ -58,14 +58,17 @@ class GmxEngine:
 
 
 class DistPageRank:
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, always_exchange=False):
         self.engine = engine
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.initialized = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.initialized else 1
+        # always_exchange: issue the collectives even with one rank (exercises the RCCL path on a 1-GPU box)
+        self.always_exchange = always_exchange and self.initialized
         self.cnt = 0
 
     def _exchange(self):
-        if self.world == 1:
+        if self.world == 1 and not self.always_exchange:
             return
         full = self.engine.contrib_full()
         mine = self.engine.contrib_slice()
@@ -89,7 +92,7 @@ class DistPageRank:
 
     def diff(self):
         t = self.engine.diff_tensor()
-        if self.world > 1:
+        if self.world > 1 or self.always_exchange:
             t = t.clone()
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return float(t.item())
