@@ -245,3 +245,88 @@ def test_dist_engine_world1_and_kernel_timing(gmx):
     assert cnt == it and n == cnt and ms > 0
     assert rel_err(eng.download(), want) < PR_RTOL_F32
     g.free()
+
+
+def _check_all_kernels(gmx, og, root=0, tc=True, pr_tol=PR_RTOL_F64):
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    want, it, _ = po.pagerank(og, 0.001, 0.85, 100)
+    for opts in (1, 3, 5, 7):
+        st = gmx.PageRankState(g, 8, 0, 1, opts)
+        st.reset(0.85)
+        for _ in range(it):
+            st.step()
+        got = st.download()
+        if og.N:
+            assert rel_err(got, want) < pr_tol, (opts, rel_err(got, want))
+        st.free()
+    r64, s64 = g.pagerank(0.001, 0.85, 100, np.float64)
+    assert s64["iterations"] == (it if og.N else 0)
+    dist, _ = g.hop_dist(root)
+    assert np.array_equal(dist, po.bfs_queue(og, root))
+    if tc:
+        assert g.triangle_counting()[0] == po.triangle_counting_merge(og)
+    g.free()
+
+
+def test_edge_case_hub_rows_spanning_many_blocks(gmx):
+    """A star with 200 000 leaves (both directions) plus a ring: one in-row / out-row of 200 000 entries
+    spans ~400 merge-path blocks and every slice; the other rows have 2-3 entries."""
+    n = 200001
+    leaves = np.arange(1, n, dtype=np.int32)
+    src = np.concatenate([np.zeros(n - 1, np.int32), leaves, leaves])
+    dst = np.concatenate([leaves, np.zeros(n - 1, np.int32), np.roll(leaves, 1)])
+    og = po.graph_from_edges(n, src, dst)
+    # the CPU adds the hub's 200 000 terms one by one (rounding bound n*eps = 2.2e-11), the device in a tree
+    _check_all_kernels(gmx, og, root=5, pr_tol=5e-11)
+
+
+def test_edge_case_mostly_empty_rows(gmx):
+    """2^20 vertices, 3000 edges: long runs of empty rows between the few non-empty ones."""
+    rng = np.random.default_rng(11)
+    V = 1 << 20
+    src = rng.integers(0, V, 3000).astype(np.int32)
+    dst = rng.integers(0, V, 3000).astype(np.int32)
+    og = po.graph_from_edges(V, src, dst)
+    _check_all_kernels(gmx, og, root=int(src[0]))
+
+
+def test_edge_case_duplicate_edges_and_self_loops(gmx):
+    """Multi-edges and self loops are kept by the reference (graph_gen.cc:265-266; hand-built graphs)."""
+    rng = np.random.default_rng(3)
+    V = 300
+    src = rng.integers(0, V, 20000).astype(np.int32)
+    dst = rng.integers(0, 40, 20000).astype(np.int32)       # few destinations: many duplicates
+    src = np.concatenate([src, np.arange(V, dtype=np.int32)])  # + one self loop per vertex
+    dst = np.concatenate([dst, np.arange(V, dtype=np.int32)])
+    og = po.graph_from_edges(V, src, dst)
+    _check_all_kernels(gmx, og, root=1)
+
+
+def test_edge_case_empty_graphs(gmx):
+    for V in (0, 1, 5):
+        begin = np.zeros(V + 1, np.int32)
+        g = gmx.Graph.upload(begin, np.zeros(0, np.int32), begin, np.zeros(0, np.int32))
+        rank, st = g.pagerank()
+        assert len(rank) == V
+        if V:
+            # no edges: every vertex gets (1-d)/N after the first sweep, diff = |that - 1/N| * N > e, second sweep converges
+            og = po.Graph(V, begin, np.zeros(0, np.int32), begin, np.zeros(0, np.int32))
+            want, it, _ = po.pagerank(og)
+            assert st["iterations"] == it and np.allclose(rank, want, rtol=1e-15)
+            dist, _ = g.hop_dist(0)
+            assert dist[0] == 0 and (dist[1:] == INT_MAX).all()
+        assert g.triangle_counting()[0] == 0
+        g.free()
+
+
+def test_bad_arguments_are_reported(gmx):
+    with pytest.raises(gmx.GmxError):
+        gmx.Graph.upload(np.array([0, 2], np.int32), np.array([0], np.int32))      # begin[V] != E
+    with pytest.raises(gmx.GmxError):
+        gmx.Graph.from_edges(4, np.array([0, 9], np.int32), np.array([1, 2], np.int32))   # endpoint out of range
+    with pytest.raises(gmx.GmxError):
+        gmx.Graph.rmat(64, 1024, a=0.6, b=0.3, c=0.2)                              # a+b+c >= 1 (graph_gen.cc:161)
+    g = gmx.Graph.upload(np.array([0, 1, 1], np.int32), np.array([1], np.int32), flags=gmx.GMX_GRAPH_NO_REVERSE)
+    with pytest.raises(gmx.GmxError):
+        g.pagerank()                                                               # needs the reverse CSR
+    g.free()
