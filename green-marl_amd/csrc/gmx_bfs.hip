@@ -111,20 +111,22 @@ bfs_topdown_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict_
     if ((tid & 63) == 0 && inspected) atomicAdd(&ctr->edges, inspected);
 }
 
-// bitmap of the vertices in cur_q
-__global__ void bfs_queue_to_bitmap_kernel(const int32_t* __restrict__ q, int64_t n, uint32_t* __restrict__ bm) {
-    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t stride = (int64_t) gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        int32_t v = q[i];
-        atomicOr(&bm[v >> 5], 1u << (v & 31));
+// frontier bitmap of a level straight from dist[] (coalesced reads, one __ballot per 64 vertices, no atomics)
+__global__ void bfs_level_bitmap_kernel(const int32_t* __restrict__ dist, int64_t V, int32_t level,
+                                        unsigned long long* __restrict__ bm64) {
+    int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    const int64_t vend = (V + 63) / 64 * 64;
+    for (; v < vend; v += stride) {
+        const unsigned long long m = __ballot(v < V && dist[v] == level);
+        if ((threadIdx.x & 63) == 0) bm64[v >> 6] = m;
     }
 }
 
 // one thread per vertex; unvisited vertices look for a parent in the frontier bitmap
 __global__ void __launch_bounds__(BFS_THREADS)
 bfs_bottomup_kernel(const int32_t* __restrict__ r_begin, const int32_t* __restrict__ r_node_idx, int64_t V,
-                    int32_t level, const uint32_t* __restrict__ frontier_bm, uint32_t* __restrict__ next_bm,
+                    int32_t level, const uint32_t* __restrict__ frontier_bm,
                     int32_t* __restrict__ dist, bfs_counters* __restrict__ ctr) {
     int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t) gridDim.x * blockDim.x;
@@ -137,7 +139,6 @@ bfs_bottomup_kernel(const int32_t* __restrict__ r_begin, const int32_t* __restri
             inspected++;
             if (frontier_bm[w >> 5] & (1u << (w & 31))) {
                 dist[t] = level + 1;
-                atomicOr(&next_bm[t >> 5], 1u << (t & 31));
                 found_cnt++;
                 break;
             }
@@ -154,17 +155,18 @@ bfs_bottomup_kernel(const int32_t* __restrict__ r_begin, const int32_t* __restri
     }
 }
 
-__global__ void bfs_bitmap_to_queue_kernel(const uint32_t* __restrict__ bm, int64_t V, int32_t* __restrict__ q,
-                                           unsigned long long* __restrict__ qcount) {
+// queue of a level straight from dist[] (ballot-aggregated append)
+__global__ void bfs_level_queue_kernel(const int32_t* __restrict__ dist, int64_t V, int32_t level,
+                                       int32_t* __restrict__ q, unsigned long long* __restrict__ qcount) {
     int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t stride = (int64_t) gridDim.x * blockDim.x;
-    int64_t vend = (V + stride - 1) / stride * stride;  // keep waves converged
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    const int64_t vend = (V + 63) / 64 * 64;
     for (; v < vend; v += stride) {
-        bool in = v < V && (bm[v >> 5] & (1u << (v & 31)));
-        unsigned long long m = __ballot(in);
+        const bool in = v < V && dist[v] == level;
+        const unsigned long long m = __ballot(in);
         if (m) {
-            int lane = threadIdx.x & 63;
-            int leader = __ffsll((long long) m) - 1;
+            const int lane = threadIdx.x & 63;
+            const int leader = __ffsll((long long) m) - 1;
             unsigned long long base = 0;
             if (lane == leader) base = atomicAdd(qcount, (unsigned long long) __popcll(m));
             base = __shfl(base, leader, 64);
@@ -188,14 +190,14 @@ extern "C" int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host,
     const bool root_ok = root >= 0 && root < V;   // a root outside the graph reaches nothing
 
     dbuf<int32_t> dist, q0, q1;
-    dbuf<uint32_t> bm0, bm1;
+    dbuf<unsigned long long> bm;
     dbuf<bfs_counters> ctr;
     dbuf<unsigned long long> qcount;
     dbuf<int32_t> deg;
     dbuf<int64_t> off;
     dbuf<char> scan_tmp;
     size_t scan_bytes = 0;
-    const size_t bmw = (size_t) ((V + 31) / 32);
+    const size_t bmw = (size_t) ((V + 63) / 64);
     GMX_CHECK(dist.alloc((size_t) V));
     GMX_CHECK(q0.alloc((size_t) V));
     GMX_CHECK(q1.alloc((size_t) V));
@@ -206,10 +208,7 @@ extern "C" int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host,
     GMX_HIP(rocprim::inclusive_scan(nullptr, scan_bytes, deg.p, off.p + 1, (size_t) V, rocprim::plus<int64_t>(), 0));
     GMX_CHECK(scan_tmp.alloc(scan_bytes));
     const bool can_bottom_up = g->has_reverse;
-    if (can_bottom_up) {
-        GMX_CHECK(bm0.alloc(bmw));
-        GMX_CHECK(bm1.alloc(bmw));
-    }
+    if (can_bottom_up) GMX_CHECK(bm.alloc(bmw));
 
     hipEvent_t ev0, ev1;
     GMX_HIP(hipEventCreate(&ev0));
@@ -227,7 +226,7 @@ extern "C" int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host,
     }
     int32_t* cur_q = q0.p;
     int32_t* next_q = q1.p;
-    bool frontier_is_bitmap = false;     // true: frontier lives in bm0 (bottom-up produced it)
+    bool frontier_is_bitmap = false;     // true: the last level ran bottom-up (no queue exists for the frontier)
     const int64_t bu_threshold = V / 20; // RRD_THRESHOLD = 0.05 (gm_bfs_template.h:359)
     int64_t explored = 0;                // out-edges of the frontiers expanded so far
 
@@ -251,19 +250,17 @@ extern "C" int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host,
             explored += m_f;
         }
         if (bottom_up) {
-            if (!frontier_is_bitmap) {
-                GMX_HIP(hipMemsetAsync(bm0.p, 0, bmw * 4, 0));
-                hipLaunchKernelGGL(bfs_queue_to_bitmap_kernel, dim3(grid_for(cur_count)), dim3(BFS_THREADS), 0, 0, cur_q, cur_count, bm0.p);
-            }
-            GMX_HIP(hipMemsetAsync(bm1.p, 0, bmw * 4, 0));
+            // the frontier of this level is {v : dist[v] == level}, whichever direction produced it
+            hipLaunchKernelGGL(bfs_level_bitmap_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
+                               (const int32_t*) dist.p, V, level, bm.p);
             hipLaunchKernelGGL(bfs_bottomup_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 32)), dim3(BFS_THREADS), 0, 0,
-                               g->r_begin.p, g->r_node_idx.p, V, level, bm0.p, bm1.p, dist.p, ctr.p);
-            uint32_t* t = bm0.p; bm0.p = bm1.p; bm1.p = t;
+                               g->r_begin.p, g->r_node_idx.p, V, level, (const uint32_t*) bm.p, dist.p, ctr.p);
             frontier_is_bitmap = true;
         } else {
             if (frontier_is_bitmap) {  // came back from bottom-up: rebuild the queue, then its edge offsets
                 GMX_HIP(hipMemsetAsync(qcount.p, 0, sizeof(unsigned long long), 0));
-                hipLaunchKernelGGL(bfs_bitmap_to_queue_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, bm0.p, V, cur_q, qcount.p);
+                hipLaunchKernelGGL(bfs_level_queue_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
+                                   (const int32_t*) dist.p, V, level, cur_q, qcount.p);
                 frontier_is_bitmap = false;
                 hipLaunchKernelGGL(bfs_degree_kernel, dim3(grid_for(cur_count)), dim3(BFS_THREADS), 0, 0, g->begin.p, cur_q, cur_count, deg.p);
                 size_t tb = scan_bytes;
