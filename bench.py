@@ -131,6 +131,14 @@ def main():
     gteps = graph.E / (ms_per_step * 1e-3) / 1e9
     achieved = work["algorithmic_bytes"] / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
 
+    # HBM bytes per step measured offline with rocprofv3 --pmc on this same command (committed under profiles/)
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "bench_traffic.json")))
+        traffic = tj.get("scale%d_%s_opt%d_gpus%d" % (args.scale, args.dtype, options, world))
+    except (OSError, ValueError):
+        pass
+
     if rank == 0:
         out = {
             "metric": "edges/s (GTEPS) per PageRank iter, RMAT-%d" % args.scale,
@@ -142,7 +150,7 @@ def main():
                        "partition": "1-D vertex, %d rank(s), all-gather of contribution slices" % world,
                        "options": options, "setup_s": round(setup_s, 2), "last_diff": last_diff},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": engine.state.kernel_name(), "kernel_ms": kernel_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": work["algorithmic_bytes"]},
             "cpu_baseline": cpu,

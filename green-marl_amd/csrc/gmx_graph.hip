@@ -550,6 +550,12 @@ extern "C" int gmx_graph_symmetrize(const gmx_graph_t* g, gmx_graph_t** out) {
 
 // ------------------------------------------------------------------ misc
 extern "C" int gmx_graph_free(gmx_graph_t* g) {
+    if (g) {
+        for (gmx_pr*& p : g->pr_cache) {
+            if (p) gmx_pr_free(p);
+            p = nullptr;
+        }
+    }
     delete g;
     return GMX_OK;
 }

@@ -73,6 +73,9 @@ struct gmx_graph {
     // original numbering, rows ascending (semi-sorted)
     dbuf<int32_t> begin, node_idx, r_begin, r_node_idx;
     int device = 0;
+    // PageRank plans built by the whole-kernel entries (fp32, fp64), kept for the next call on the same
+    // graph: the plan is graph preprocessing, like the reverse CSR.  Freed with the graph.
+    gmx_pr* pr_cache[2] = {nullptr, nullptr};
 };
 
 // ---- graph construction helpers (gmx_graph.hip) ----

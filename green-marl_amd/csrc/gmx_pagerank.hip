@@ -1222,8 +1222,9 @@ static int pagerank_entry(gmx_graph_t* g, double e, double d, int32_t max_iter, 
     GMX_REQUIRE(g && rank_host, "NULL argument");
     if (stats) memset(stats, 0, sizeof(*stats));
     if (g->V == 0) return GMX_OK;
-    gmx_pr_t* p = nullptr;
-    GMX_CHECK(gmx_pr_create(g, (int) sizeof(S), 0, 1, gmx_pr_default_options(g->V, 1), &p));
+    gmx_pr_t*& cached = g->pr_cache[sizeof(S) == 4 ? 0 : 1];
+    if (cached == nullptr) GMX_CHECK(gmx_pr_create(g, (int) sizeof(S), 0, 1, gmx_pr_default_options(g->V, 1), &cached));
+    gmx_pr_t* p = cached;
     int st = gmx_pr_reset(p, d);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double diff = 0.0;
@@ -1264,7 +1265,6 @@ static int pagerank_entry(gmx_graph_t* g, double e, double d, int32_t max_iter, 
     }
     if (ev0) (void) hipEventDestroy(ev0);
     if (ev1) (void) hipEventDestroy(ev1);
-    gmx_pr_free(p);
     return st;
 }
 
