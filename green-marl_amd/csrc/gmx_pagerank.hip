@@ -1170,13 +1170,13 @@ extern "C" int gmx_pr_download(gmx_pr_t* p, void* rank_host) {
     return GMX_OK;
 }
 
-// Variant choice by size (measured, profiles/round1_*): below 2^25 vertices the contribution
-// vector mostly lives in L2 / Infinity Cache and the unsliced wave kernel with an LDS hot tile wins;
-// above, splitting the sources over the XCD L2s pays for its partial-sum pass.
+// Variant choice by size (measured on RMAT, edge factor 16): up to 2^21 vertices the contribution
+// vector (8 MiB fp32) lives in L2 and the unsliced kernel with an LDS hot tile wins; from 2^22 on,
+// splitting the sources over the XCD L2s pays for its partial-sum pass (RMAT-24: 1.21 vs 1.53 ms).
 extern "C" uint32_t gmx_pr_default_options(int64_t V, int nranks) {
     uint32_t o = GMX_PR_RELABEL;
     if (nranks == 1) o |= GMX_PR_HOT_LDS;
-    if (V > (1LL << 25)) o |= GMX_PR_SLICED;
+    if (V > (1LL << 21)) o |= GMX_PR_SLICED;
     return o;
 }
 
