@@ -91,7 +91,9 @@ struct gmx_pr {
     // XCD-sliced variant
     int ns = 0;
     pr_sliced_args sl;
-    dbuf<int32_t> sl_rb, sl_ridx, sl_rowid;
+    dbuf<int32_t> sl_rb, sl_ridx, sl_rowid, sl_active;   // sl_active: local rows with in-edges
+    dbuf<uint8_t> sl_is_active;
+    int64_t sl_nactive = 0;
     dbuf<pr_blk> sl_blk;
     dbuf<double> sl_part_first, sl_part_last;
     dbuf<char> sl_partial;
@@ -731,21 +733,51 @@ __global__ void pr_sliced_fixup_kernel(pr_sliced_args a, int64_t rows) {
     pr_fixup_one<S>(sd.blk, sd.nblk, sd.crows, sd.rb, k, out, unused);
 }
 
-// sum the slices in fixed order and apply the PageRank update (streaming, one thread per row)
+// Sum the slices in fixed order and apply the PageRank update.  Only rows that have in-edges are
+// visited (active[]): a row without in-edges gets (1-d)/N in the first sweep and never changes again
+// (SURVEY.md appendix A), so pr_inactive_first_kernel settles those once, right after a reset.
 template <typename S>
 __global__ void __launch_bounds__(256)
-pr_combine_kernel(pr_sliced_args a, int64_t rows, const int32_t* __restrict__ outdeg, S* __restrict__ rk,
+pr_combine_kernel(pr_sliced_args a, const int32_t* __restrict__ active, int64_t nactive,
+                  const int32_t* __restrict__ outdeg, S* __restrict__ rk,
                   S* __restrict__ contrib_next_owned, double base, double d, double* __restrict__ diff_part) {
     __shared__ double s_red[256 / 64];
     double diff_acc = 0.0;
-    int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
-    for (; r < rows; r += stride) {
+    for (; i < nactive; i += stride) {
+        const int64_t r = __builtin_nontemporal_load(active + i);
         double sum = 0.0;
         for (int sl = 0; sl < a.ns; sl++) sum += (double) __builtin_nontemporal_load((const S*) a.s[sl].partial + r);
         pr_finalize<S>(r, sum, base, d, rk, outdeg, contrib_next_owned, diff_acc);
     }
     pr_block_diff<256>(diff_acc, s_red, diff_part + blockIdx.x);
+}
+
+// First sweep after a reset: rows with no in-edges.  Writes their (from now on constant) contribution
+// into BOTH replicas, since later sweeps only rewrite the active rows of the replica they produce.
+template <typename S>
+__global__ void __launch_bounds__(256)
+pr_inactive_first_kernel(const uint8_t* __restrict__ is_active, int64_t rows, const int32_t* __restrict__ outdeg,
+                         S* __restrict__ rk, S* __restrict__ contrib_cur_owned, S* __restrict__ contrib_next_owned,
+                         double base, double d, double* __restrict__ diff_part) {
+    __shared__ double s_red[256 / 64];
+    double diff_acc = 0.0;
+    int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; r < rows; r += stride) {
+        if (is_active[r]) continue;
+        pr_finalize<S>(r, 0.0, base, d, rk, outdeg, contrib_next_owned, diff_acc);
+        contrib_cur_owned[r] = contrib_next_owned[r];
+    }
+    pr_block_diff<256>(diff_acc, s_red, diff_part + blockIdx.x);
+}
+
+__global__ void pr_mark_active_kernel(const uint64_t* __restrict__ keys, int64_t n, int64_t row_lo, uint8_t* __restrict__ is_active) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride)
+        if (i == 0 || (keys[i - 1] >> 32) != (keys[i] >> 32)) is_active[(int64_t) (keys[i] >> 32) - row_lo] = 1;
 }
 
 __global__ void pr_diff_reduce_kernel(const double* __restrict__ part, int64_t n, double* __restrict__ out) {
@@ -915,6 +947,22 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 hipLaunchKernelGGL(pr_slice_offsets_kernel, dim3(1), dim3(64), 0, s, (const uint8_t*) sk2.p, El, ns, off.p);
                 int64_t hoff[PR_MAX_SLICES + 1];
                 if (hipMemcpy(hoff, off.p, sizeof(int64_t) * (ns + 1), hipMemcpyDeviceToHost) != hipSuccess) { gmx_set_error("pr plan: slice offsets copy failed"); st = GMX_ERR_HIP; break; }
+                // rows with in-edges (the only ones the combine pass has to visit)
+                {
+                    if ((st = p->sl_is_active.alloc((size_t) (rows ? rows : 1))) || (st = p->sl_active.alloc((size_t) (rows ? rows : 1)))) break;
+                    if (hipMemsetAsync(p->sl_is_active.p, 0, (size_t) (rows ? rows : 1), s) != hipSuccess) { gmx_set_error("pr plan: memset failed"); st = GMX_ERR_HIP; break; }
+                    if (El > 0) hipLaunchKernelGGL(pr_mark_active_kernel, dim3(grid_for(El)), dim3(256), 0, s, sorted + hb[0], El, p->row_lo, p->sl_is_active.p);
+                    dbuf<int64_t> cnt;
+                    if ((st = cnt.alloc(1))) break;
+                    size_t tb = 0;
+                    rocprim::counting_iterator<int32_t> ids(0);
+                    he = rocprim::select(nullptr, tb, ids, (const uint8_t*) p->sl_is_active.p, p->sl_active.p, cnt.p, (size_t) rows, s);
+                    dbuf<char> tmp3;
+                    if (he == hipSuccess && (st = tmp3.alloc(tb))) break;
+                    if (he == hipSuccess) he = rocprim::select((void*) tmp3.p, tb, ids, (const uint8_t*) p->sl_is_active.p, p->sl_active.p, cnt.p, (size_t) rows, s);
+                    if (he == hipSuccess) he = hipMemcpy(&p->sl_nactive, cnt.p, sizeof(int64_t), hipMemcpyDeviceToHost);
+                    if (he != hipSuccess) { gmx_set_error("pr plan: active-row list failed: %s", hipGetErrorString(he)); st = GMX_ERR_HIP; break; }
+                }
                 // compact rows: one (slice,row) pair per row that has at least one edge in the slice
                 dbuf<int32_t> flag, pos;
                 if ((st = flag.alloc((size_t) El + 1)) || (st = pos.alloc((size_t) El + 1)) || (st = p->sl_ridx.alloc((size_t) El))) break;
@@ -994,7 +1042,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
         }
         // merge-path blocks
         int64_t total = p->rows + p->El;
-        p->nblk = p->ns > 0 ? PR_COMBINE_GRID : (total + p->items - 1) / p->items;   // sliced: diff partials of the combine grid
+        p->nblk = p->ns > 0 ? 2 * PR_COMBINE_GRID : (total + p->items - 1) / p->items;   // sliced: diff partials of the combine (+ first-sweep) grid
         if ((st = p->blk.alloc((size_t) p->nblk + 1))) break;
         if (p->ns == 0)
             hipLaunchKernelGGL(pr_blocks_kernel, dim3(grid_for(p->nblk + 1, 256, 1 << 30)), dim3(256), 0, s,
@@ -1096,9 +1144,16 @@ static void launch_sliced(gmx_pr* p, hipStream_t s) {
         }
         hipLaunchKernelGGL(pr_sliced_fixup_kernel<S>, dim3((unsigned) ((maxblk + 255) / 256), p->ns), dim3(256), 0, s, p->sl, p->rows);
     }
-    hipLaunchKernelGGL(pr_combine_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, p->sl, p->rows, p->outdeg.p, (S*) p->rk.p,
-                       next_owned, base, p->d, p->diff_part.p);
-    hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) p->diff_part.p, (int64_t) PR_COMBINE_GRID, p->diff.p);
+    hipLaunchKernelGGL(pr_combine_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, p->sl, (const int32_t*) p->sl_active.p, p->sl_nactive,
+                       p->outdeg.p, (S*) p->rk.p, next_owned, base, p->d, p->diff_part.p);
+    int64_t nparts = PR_COMBINE_GRID;
+    if (p->cnt == 0) {   // first sweep after a reset: settle the rows without in-edges once
+        S* cur_owned = (S*) p->contrib[p->cur].p + p->row_lo;
+        hipLaunchKernelGGL(pr_inactive_first_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, (const uint8_t*) p->sl_is_active.p, p->rows,
+                           p->outdeg.p, (S*) p->rk.p, cur_owned, next_owned, base, p->d, p->diff_part.p + PR_COMBINE_GRID);
+        nparts = 2 * PR_COMBINE_GRID;
+    }
+    hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) p->diff_part.p, nparts, p->diff.p);
 }
 
 extern "C" int gmx_pr_step(gmx_pr_t* p, void* stream) {
