@@ -70,6 +70,7 @@ struct gmx_pr {
     int64_t rows_real = 0;  // vertices owned by this rank
     int64_t row_lo = 0;   // first owned row in the internal numbering
     int64_t El = 0;       // edges of the owned rows
+    int64_t exchange_count = 0;   // leading entries of a rank's range that other ranks can ever read
     dbuf<int32_t> inv;    // internal id -> original id for owned rows [rows]
     dbuf<int32_t> rb_own, ridx_own;
     const int32_t* rb = nullptr;    // local r_begin' [rows+1]
@@ -190,6 +191,17 @@ __global__ void pr_local_csr_kernel(const uint64_t* __restrict__ keys, int64_t E
         }
         rb[r] = (int32_t) (lo - k_lo);
     }
+}
+
+// first position of a sorted uint32 array holding a value >= t
+__global__ void pr_key32_bound_kernel(const uint32_t* __restrict__ keys, int64_t n, uint32_t t, int64_t* __restrict__ out) {
+    if (threadIdx.x || blockIdx.x) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < t) lo = mid + 1; else hi = mid;
+    }
+    out[0] = lo;
 }
 
 __global__ void pr_key_bound_kernel(const uint64_t* __restrict__ keys, int64_t E, uint64_t t0, uint64_t t1,
@@ -857,6 +869,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
         p->rows_real = hi > p->row_lo ? hi - p->row_lo : 0;
     }
     p->rows = p->ns > 0 ? p->slice : p->rows_real;
+    p->exchange_count = p->slice;
     p->hot = (options & GMX_PR_HOT_LDS) != 0 && relabel && nranks == 1;
     p->items = PRW_ITEMS;
 
@@ -896,6 +909,17 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                     he = hipStreamSynchronize(s);
                 }
                 if (he != hipSuccess) { gmx_set_error("pr plan: degree sort failed: %s", hipGetErrorString(he)); st = GMX_ERR_HIP; break; }
+                // vertices with out-degree 0 are never gathered; in the degree order they form the tail of every
+                // rank's range, so only a prefix of each range has to travel between ranks
+                dbuf<int64_t> nzd;
+                if ((st = nzd.alloc(2))) break;
+                hipLaunchKernelGGL(pr_key32_bound_kernel, dim3(1), dim3(64), 0, s, (const uint32_t*) key2.p, V, 0x7fffffffu, nzd.p);
+                int64_t nz = V;
+                if (hipMemcpy(&nz, nzd.p, sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) { gmx_set_error("pr plan: copy failed"); st = GMX_ERR_HIP; break; }
+                int64_t need = (nz + nranks - 1) / nranks;
+                const int64_t unit = p->ns > 0 ? ((int64_t) p->ns << PR_RUN_SHIFT) : 1;
+                need = (need + unit - 1) / unit * unit;
+                p->exchange_count = need < p->slice ? need : p->slice;
             } else {
                 hipLaunchKernelGGL(pr_perm_kernel, dim3(grid_for(V)), dim3(256), 0, s, (const int32_t*) nullptr, V, p->slice, nranks, 0, perm.p);
             }
@@ -1185,6 +1209,12 @@ extern "C" int gmx_pr_contrib_slice(gmx_pr_t* p, void** dev_ptr, int64_t* count)
     GMX_REQUIRE(p && dev_ptr && count, "NULL argument");
     *dev_ptr = p->contrib[p->cur].p + (size_t) p->row_lo * p->elem;
     *count = p->slice;
+    return GMX_OK;
+}
+
+extern "C" int gmx_pr_exchange_count(gmx_pr_t* p, int64_t* count) {
+    GMX_REQUIRE(p && count, "NULL argument");
+    *count = p->exchange_count;
     return GMX_OK;
 }
 

@@ -53,6 +53,9 @@ class GmxEngine:
     def diff_tensor(self):
         return self._wrap(self.state.diff_dev())
 
+    def exchange_count(self):
+        return self.state.exchange_count()
+
     def download(self, out=None):
         return self.state.download(out)
 
@@ -72,8 +75,15 @@ class DistPageRank:
             return
         full = self.engine.contrib_full()
         mine = self.engine.contrib_slice()
+        n = mine.numel()
+        need = self.engine.exchange_count() if hasattr(self.engine, "exchange_count") else n
         backend = dist.get_backend(self.group)
-        if backend == "gloo":
+        if need < n:
+            # only the leading `need` entries of every rank's range are ever read by others (the rest are
+            # vertices without out-edges): gather those prefixes straight into their places in the replica
+            parts = [full[r * n:r * n + need] for r in range(self.world)]
+            dist.all_gather(parts, mine[:need].clone(), group=self.group)
+        elif backend == "gloo":
             parts = list(full.chunk(self.world))
             dist.all_gather(parts, mine.clone(), group=self.group)
         else:

@@ -45,7 +45,7 @@ EXPORTS = [
     "gmx_graph_num_nodes", "gmx_graph_num_edges", "gmx_graph_download",
     "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_triangle_counting",
     "gmx_pr_create", "gmx_pr_free", "gmx_pr_reset", "gmx_pr_step", "gmx_pr_contrib_slice",
-    "gmx_pr_contrib_full", "gmx_pr_diff_ptr", "gmx_pr_diff", "gmx_pr_download", "gmx_pr_work",
+    "gmx_pr_contrib_full", "gmx_pr_exchange_count", "gmx_pr_diff_ptr", "gmx_pr_diff", "gmx_pr_download", "gmx_pr_work",
     "gmx_pr_timing", "gmx_pr_kernel_time", "gmx_pr_kernel_name", "gmx_pr_default_options",
 ]
 
@@ -86,6 +86,7 @@ def lib():
         L.gmx_pr_contrib_slice.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
         L.gmx_pr_contrib_full.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
         L.gmx_pr_diff_ptr.argtypes = [vp, C.POINTER(vp)]
+        L.gmx_pr_exchange_count.argtypes = [vp, C.POINTER(i64)]
         L.gmx_pr_diff.argtypes = [vp, vp, C.POINTER(C.c_double)]
         L.gmx_pr_download.argtypes = [vp, vp]
         L.gmx_pr_work.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
@@ -282,6 +283,11 @@ class PageRankState:
         p, n = C.c_void_p(), C.c_int64(0)
         _ck(lib().gmx_pr_contrib_full(self._h, C.byref(p), C.byref(n)))
         return DevArray(p.value, n.value, self._typestr())
+
+    def exchange_count(self):
+        n = C.c_int64(0)
+        _ck(lib().gmx_pr_exchange_count(self._h, C.byref(n)))
+        return n.value
 
     def diff_dev(self):
         p = C.c_void_p()

@@ -148,6 +148,9 @@ int gmx_pr_step(gmx_pr_t* p, void* stream);
  * whole replica. */
 int gmx_pr_contrib_slice(gmx_pr_t* p, void** dev_ptr, int64_t* count);
 int gmx_pr_contrib_full(gmx_pr_t* p, void** dev_ptr, int64_t* count);
+/* Leading entries of every rank's range that have to be exchanged: vertices without out-edges are never
+ * gathered and sit at the end of each range in the degree order (same value on every rank; <= slice count). */
+int gmx_pr_exchange_count(gmx_pr_t* p, int64_t* count);
 /* Device pointer to the fp64 `diff` partial of the last step (1 element). */
 int gmx_pr_diff_ptr(gmx_pr_t* p, void** dev_ptr);
 /* Blocking: returns diff of the last step (local rows only). */

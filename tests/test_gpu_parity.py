@@ -210,9 +210,11 @@ def test_pagerank_partitioned_ranks_in_one_process(gmx, nranks, options):
         fulls = [torch.as_tensor(s.contrib_full(), device="cuda") for s in states]
         slices = [torch.as_tensor(s.contrib_slice(), device="cuda") for s in states]
         n = slices[0].numel()
+        need = states[0].exchange_count()        # prefix of every range that other ranks can read
+        assert all(s.exchange_count() == need for s in states) and 0 <= need <= n
         for dst in fulls:
             for r, src in enumerate(slices):
-                dst[r * n:(r + 1) * n].copy_(src)
+                dst[r * n:r * n + need].copy_(src[:need])
         torch.cuda.synchronize()
 
     for s in states:
