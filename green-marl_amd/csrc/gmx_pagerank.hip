@@ -401,77 +401,97 @@ struct prw_partial {
     __device__ __forceinline__ int32_t preload(int64_t r) const { return __builtin_nontemporal_load(rowid + r); }
 };
 
-// Consume one block whose index slice is already in ix[] (prefetched) and prefetch the next block's
-// slice (ridx_n + e0n, nen entries) into ixn[] behind the gathers.  hot_lim == 0 disables the tile.
+// A wave keeps THREE blocks in flight (software pipeline, no barrier anywhere):
+//   stage A  prw_load_idx : the index slice of block k+2 is loaded into registers;
+//   stage B  prw_issue    : for block k+1 (indices already there) the row starts, the per-row data of the
+//                           output policy and the contribution gathers are issued into registers;
+//   stage C  prw_consume  : block k (everything already in registers) is staged in the wave's LDS slice,
+//                           reduced and written out.
+// So the gathers of the next block and the index stream of the one after are always outstanding while a
+// block is being reduced.
+template <typename S>
+struct prw_regs {
+    int32_t rbv[PRW_ROWU];   // row starts
+    int32_t od[PRW_ROWU];    // out-degree (final) / compact row id (partial) of the rows that finish in the block
+    S old[PRW_ROWU];         // old rank (final only)
+    S vv[PRW_PER];           // gathered contributions
+};
+
+template <bool NT>
+__device__ __forceinline__ void prw_load_idx(const int32_t* __restrict__ ridx, int e0, int ne, int32_t (&ix)[PRW_PER]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int u = 0; u < PRW_PER; u++) {
+        const int j = lane + 64 * u;
+        ix[u] = -1;
+        if (j < ne) ix[u] = NT ? __builtin_nontemporal_load(ridx + e0 + j) : ridx[e0 + j];
+    }
+}
+
+// hot_lim == 0 disables the LDS tile; hot_shift: ids are mapped to tile slots of the home slice.
+template <typename S, typename OUT>
+__device__ __forceinline__ void prw_issue(const S* __restrict__ s_hot, int hot_lim, int hot_shift, int hot_sl_shift,
+                                          pr_blk b0, pr_blk b1,
+                                          const int32_t* __restrict__ rb, const int32_t* __restrict__ outdeg,
+                                          const S* __restrict__ rk_old, const S* __restrict__ contrib,
+                                          const int32_t (&ix)[PRW_PER], const OUT& out, prw_regs<S>& g) {
+    const int lane = threadIdx.x & 63;
+    const int r0 = b0.r, nr = b1.r - b0.r + 1;
+#pragma unroll
+    for (int u = 0; u < PRW_ROWU; u++) {
+        const int i = lane + 64 * u;
+        g.rbv[u] = 0;
+        g.od[u] = -1;
+        g.old[u] = (S) 0;
+        if (i < nr) {
+            g.rbv[u] = __builtin_nontemporal_load(rb + r0 + i);
+            if (i < nr - 1) {
+                if (OUT::needs_vertex_data) {
+                    g.od[u] = __builtin_nontemporal_load(outdeg + r0 + i);
+                    g.old[u] = __builtin_nontemporal_load(rk_old + r0 + i);
+                } else g.od[u] = out.preload((int64_t) r0 + i);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PRW_PER; u++) {
+        g.vv[u] = (S) 0;
+        const int32_t id = ix[u];
+        if (id >= 0) {
+            // tile slot of an id of the home slice: drop the slice bits above the run offset
+            const int q = ((id >> (PR_RUN_SHIFT + hot_sl_shift)) << PR_RUN_SHIFT) | (id & ((1 << PR_RUN_SHIFT) - 1));
+            const int slot = hot_shift ? q : id;
+            if (slot < hot_lim) g.vv[u] = s_hot[slot];
+            else g.vv[u] = contrib[id];
+        }
+    }
+}
+
 // Row reduction: every lane walks exactly PRW_PER consecutive items of the block's merge path (edges
 // and row ends), so there is no divergence and no per-row loop; rows that span lanes are closed by a
 // wave-wide segmented scan of the lanes' open sums.  A finished row's sum is parked in the LDS slot of
 // the row's last edge (already consumed, hence free) and written out one lane per row, coalesced.
-template <typename S, bool NT, typename OUT>
-__device__ __forceinline__ void prw_block(prw_lds<S>* __restrict__ w, const S* __restrict__ s_hot, int hot_lim,
-                                              int hot_shift, int hot_sl_shift,
-                                              int64_t k, pr_blk b0, pr_blk b1, int64_t rows,
-                                              const int32_t* __restrict__ rb, const int32_t* __restrict__ outdeg,
-                                              const S* __restrict__ rk_old, const S* __restrict__ contrib,
-                                              const int32_t (&ix)[PRW_PER],
-                                              const int32_t* __restrict__ ridx_n, int e0n, int nen, int32_t (&ixn)[PRW_PER],
-                                              const OUT& out, double& diff_acc) {
+template <typename S, typename OUT>
+__device__ __forceinline__ void prw_consume(prw_lds<S>* __restrict__ w, int64_t k, pr_blk b0, pr_blk b1, int64_t rows,
+                                            const prw_regs<S>& g, const OUT& out, double& diff_acc) {
     const int lane = threadIdx.x & 63;
     const int r0 = b0.r, e0 = b0.e, r1 = b1.r, e1 = b1.e;
     const int ne = e1 - e0;
     const int nr = r1 - r0 + 1;
     const int nends = nr - 1;          // row-end items of this block
     const int total = nends + ne;      // path items of this block
-
-    int32_t rbv[PRW_ROWU], od[PRW_ROWU];
-    S old[PRW_ROWU];
 #pragma unroll
     for (int u = 0; u < PRW_ROWU; u++) {
         const int i = lane + 64 * u;
-        rbv[u] = 0;
-        od[u] = -1;
-        old[u] = (S) 0;
-        if (i < nr) {
-            rbv[u] = __builtin_nontemporal_load(rb + r0 + i);
-            if (i < nr - 1) {
-                if (OUT::needs_vertex_data) {
-                    od[u] = __builtin_nontemporal_load(outdeg + r0 + i);
-                    old[u] = __builtin_nontemporal_load(rk_old + r0 + i);
-                } else od[u] = out.preload((int64_t) r0 + i);
-            }
-        }
-    }
-    S vv[PRW_PER];
-#pragma unroll
-    for (int u = 0; u < PRW_PER; u++) {
-        vv[u] = (S) 0;
-        const int32_t id = ix[u];
-        if (id >= 0) {
-            // tile slot of an id of the home slice: drop the slice bits above the run offset
-            const int q = ((id >> (PR_RUN_SHIFT + hot_sl_shift)) << PR_RUN_SHIFT) | (id & ((1 << PR_RUN_SHIFT) - 1));
-            const int slot = hot_shift ? q : id;
-            if (slot < hot_lim) vv[u] = s_hot[slot];
-            else vv[u] = contrib[id];
-        }
+        if (i < nr) w->rb[i] = g.rbv[u];
     }
 #pragma unroll
     for (int u = 0; u < PRW_PER; u++) {
         const int j = lane + 64 * u;
-        ixn[u] = -1;
-        if (j < nen) ixn[u] = NT ? __builtin_nontemporal_load(ridx_n + e0n + j) : ridx_n[e0n + j];
-    }
-#pragma unroll
-    for (int u = 0; u < PRW_ROWU; u++) {
-        const int i = lane + 64 * u;
-        if (i < nr) w->rb[i] = rbv[u];
-    }
-#pragma unroll
-    for (int u = 0; u < PRW_PER; u++) {
-        const int j = lane + 64 * u;
-        if (j < ne) w->val[PRW_PAD(j)] = vv[u];
+        if (j < ne) w->val[PRW_PAD(j)] = g.vv[u];
     }
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible to all its lanes
     __builtin_amdgcn_wave_barrier();
 
     const bool first_started_here = (w->rb[0] >= e0);
@@ -541,14 +561,14 @@ __device__ __forceinline__ void prw_block(prw_lds<S>* __restrict__ w, const S* _
         if (64 * u >= nr) break;
         const int ri = lane + 64 * u;
         if (ri < nr) {
-            int lo = rbv[u] - e0;
+            int lo = g.rbv[u] - e0;
             if (lo < 0) lo = 0;
             const bool started = (ri > 0) || first_started_here;
             if (ri < nr - 1) {
                 const int hi = w->rb[ri + 1] - e0;
                 const double sum = hi > lo ? (double) w->val[PRW_PAD(hi - 1)] : 0.0;
                 if (!started) out.part_first[k] = sum;
-                else out.row((int64_t) r0 + ri, sum, od[u], old[u], diff_acc);
+                else out.row((int64_t) r0 + ri, sum, g.od[u], g.old[u], diff_acc);
             } else {
                 if (!started) out.part_first[k] = block_tail;
                 else if (r0 + ri < rows && ne > lo) out.part_last[k] = block_tail;
@@ -577,36 +597,45 @@ pr_wave_kernel(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t W = (int64_t) gridDim.x * WAVES;
-    int64_t k = (int64_t) blockIdx.x * WAVES + wv;
     prw_lds<S>* w = &lds[wv];
     prw_final<S> out{rk, contrib_next_owned, base, d, part_first, part_last};
     double diff_acc = 0.0;
-    int32_t ix[PRW_PER], ixn[PRW_PER];
-    pr_blk b0 = {0, 0}, b1 = {0, 0};
-    if (k < nblk) {
-        b0 = blk[k];
-        b1 = blk[k + 1];
-#pragma unroll
-        for (int u = 0; u < PRW_PER; u++) {
-            const int j = lane + 64 * u;
-            ix[u] = -1;
-            if (j < b1.e - b0.e) ix[u] = NT ? __builtin_nontemporal_load(ridx + b0.e + j) : ridx[b0.e + j];
-        }
+
+    // pipeline registers: C = block being reduced, B = block whose loads are in flight, A = index slice ahead
+    int64_t kC = (int64_t) blockIdx.x * WAVES + wv, kB = kC + W;
+    pr_blk c0 = {0, 0}, c1 = {0, 0}, b0 = {0, 0}, b1 = {0, 0};
+    prw_regs<S> gC, gB;
+    int32_t ixB[PRW_PER], ixA[PRW_PER];
+    if (kC < nblk) {
+        c0 = blk[kC];
+        c1 = blk[kC + 1];
+        prw_load_idx<NT>(ridx, c0.e, c1.e - c0.e, ixB);
+        prw_issue<S>(s_hot, HOT, 0, 0, c0, c1, rb, outdeg, rk, contrib, ixB, out, gC);
     }
-    while (k < nblk) {
-        const int64_t kn = k + W;
-        pr_blk n0 = {0, 0}, n1 = {0, 0};
-        if (kn < nblk) {
-            n0 = blk[kn];
-            n1 = blk[kn + 1];
+    if (kB < nblk) {
+        b0 = blk[kB];
+        b1 = blk[kB + 1];
+        prw_load_idx<NT>(ridx, b0.e, b1.e - b0.e, ixB);
+    }
+    while (kC < nblk) {
+        const int64_t kA = kB + W;
+        pr_blk a0 = {0, 0}, a1 = {0, 0};
+        if (kA < nblk) {
+            a0 = blk[kA];
+            a1 = blk[kA + 1];
+            prw_load_idx<NT>(ridx, a0.e, a1.e - a0.e, ixA);
         }
-        prw_block<S, NT, prw_final<S>>(w, s_hot, HOT, 0, 0, k, b0, b1, rows, rb, outdeg, rk, contrib, ix,
-                                             ridx, n0.e, n1.e - n0.e, ixn, out, diff_acc);
-        k = kn;
-        b0 = n0;
-        b1 = n1;
+        if (kB < nblk) prw_issue<S>(s_hot, HOT, 0, 0, b0, b1, rb, outdeg, rk, contrib, ixB, out, gB);
+        prw_consume<S>(w, kC, c0, c1, rows, gC, out, diff_acc);
+        kC = kB;
+        c0 = b0;
+        c1 = b1;
+        gC = gB;
+        kB = kA;
+        b0 = a0;
+        b1 = a1;
 #pragma unroll
-        for (int u = 0; u < PRW_PER; u++) ix[u] = ixn[u];
+        for (int u = 0; u < PRW_PER; u++) ixB[u] = ixA[u];
     }
     diff_acc = wave_sum(diff_acc);
     if (lane == 0) diff_part[(int64_t) blockIdx.x * WAVES + wv] = diff_acc;
@@ -631,7 +660,6 @@ pr_wave_sliced_kernel(pr_sliced_args a, int64_t rows, const S* __restrict__ cont
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     prw_lds<S>* w = &lds[wv];
     double unused = 0.0;
-    int32_t ix[PRW_PER], ixn[PRW_PER];
 
     // dequeue state (wave-uniform; lane 0 performs the atomic, the result is broadcast)
     long long k_next = 0, k_end = 0;
@@ -659,40 +687,60 @@ pr_wave_sliced_kernel(pr_sliced_args a, int64_t rows, const S* __restrict__ cont
         k_out = k;
         sl_out = cur;
     };
-
-    long long k, kn;
-    int sl, sln;
-    claim(k, sl);
-    pr_blk b0 = {0, 0}, b1 = {0, 0};
-    if (k >= 0) {
-        b0 = a.s[sl].blk[k];
-        b1 = a.s[sl].blk[k + 1];
-        const int32_t* ridx = a.s[sl].ridx;
-#pragma unroll
-        for (int u = 0; u < PRW_PER; u++) {
-            const int j = lane + 64 * u;
-            ix[u] = -1;
-            if (j < b1.e - b0.e) ix[u] = NT ? __builtin_nontemporal_load(ridx + b0.e + j) : ridx[b0.e + j];
-        }
-    }
-    while (k >= 0) {
-        claim(kn, sln);
-        pr_blk n0 = {0, 0}, n1 = {0, 0};
-        if (kn >= 0) {
-            n0 = a.s[sln].blk[kn];
-            n1 = a.s[sln].blk[kn + 1];
-        }
+    auto policy = [&](int sl) {
         const pr_slice_desc& sd = a.s[sl];
-        prw_partial<S> out{(S*) sd.partial, sd.rowid, sd.part_first, sd.part_last};
-        prw_block<S, NT, prw_partial<S>>(w, s_hot, (HOT > 0 && sl == home) ? HOT : 0, 1, ns_shift, (int64_t) k, b0, b1, sd.crows,
-                                               sd.rb, (const int32_t*) nullptr, (const S*) nullptr, contrib, ix,
-                                               kn >= 0 ? a.s[sln].ridx : sd.ridx, n0.e, n1.e - n0.e, ixn, out, unused);
-        k = kn;
-        sl = sln;
-        b0 = n0;
-        b1 = n1;
+        return prw_partial<S>{(S*) sd.partial, sd.rowid, sd.part_first, sd.part_last};
+    };
+
+    // pipeline registers: C = block being reduced, B = block whose loads are in flight, A = index slice ahead
+    long long kC, kB, kA;
+    int slC, slB, slA;
+    pr_blk c0 = {0, 0}, c1 = {0, 0}, b0 = {0, 0}, b1 = {0, 0};
+    prw_regs<S> gC, gB;
+    int32_t ixB[PRW_PER], ixA[PRW_PER];
+    claim(kC, slC);
+    if (kC >= 0) {
+        c0 = a.s[slC].blk[kC];
+        c1 = a.s[slC].blk[kC + 1];
+        prw_load_idx<NT>(a.s[slC].ridx, c0.e, c1.e - c0.e, ixB);
+        prw_issue<S>(s_hot, (HOT > 0 && slC == home) ? HOT : 0, 1, ns_shift, c0, c1, a.s[slC].rb,
+                     (const int32_t*) nullptr, (const S*) nullptr, contrib, ixB, policy(slC), gC);
+        claim(kB, slB);
+    } else {
+        kB = -1;
+        slB = home;
+    }
+    if (kB >= 0) {
+        b0 = a.s[slB].blk[kB];
+        b1 = a.s[slB].blk[kB + 1];
+        prw_load_idx<NT>(a.s[slB].ridx, b0.e, b1.e - b0.e, ixB);
+    }
+    while (kC >= 0) {
+        pr_blk a0 = {0, 0}, a1 = {0, 0};
+        kA = -1;
+        slA = home;
+        if (kB >= 0) {
+            claim(kA, slA);
+            if (kA >= 0) {
+                a0 = a.s[slA].blk[kA];
+                a1 = a.s[slA].blk[kA + 1];
+                prw_load_idx<NT>(a.s[slA].ridx, a0.e, a1.e - a0.e, ixA);
+            }
+            prw_issue<S>(s_hot, (HOT > 0 && slB == home) ? HOT : 0, 1, ns_shift, b0, b1, a.s[slB].rb,
+                         (const int32_t*) nullptr, (const S*) nullptr, contrib, ixB, policy(slB), gB);
+        }
+        prw_consume<S>(w, (int64_t) kC, c0, c1, a.s[slC].crows, gC, policy(slC), unused);
+        kC = kB;
+        slC = slB;
+        c0 = b0;
+        c1 = b1;
+        gC = gB;
+        kB = kA;
+        slB = slA;
+        b0 = a0;
+        b1 = a1;
 #pragma unroll
-        for (int u = 0; u < PRW_PER; u++) ix[u] = ixn[u];
+        for (int u = 0; u < PRW_PER; u++) ixB[u] = ixA[u];
     }
 }
 
