@@ -175,6 +175,19 @@ __global__ void bfs_level_queue_kernel(const int32_t* __restrict__ dist, int64_t
     }
 }
 
+// out-edges of the reached vertices (what Graph500 divides by the traversal time)
+__global__ void bfs_edges_reached_kernel(const int32_t* __restrict__ dist, const int32_t* __restrict__ begin, int64_t V,
+                                         unsigned long long* __restrict__ out) {
+    int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    unsigned long long acc = 0;
+    for (; v < V; v += stride)
+        if (dist[v] != INT_MAX) acc += (unsigned long long) (begin[v + 1] - begin[v]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
 static int grid_for(int64_t n, int block = BFS_THREADS, int max_blocks = 256 * 8) {
     int64_t b = (n + block - 1) / block;
     if (b < 1) b = 1;
@@ -287,6 +300,12 @@ extern "C" int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host,
     GMX_HIP(hipEventSynchronize(ev1));
     float ms = 0;
     (void) hipEventElapsedTime(&ms, ev0, ev1);
+    unsigned long long edges_reached = 0;
+    if (stats) {   // statistics only, outside the timed traversal
+        GMX_HIP(hipMemset(qcount.p, 0, sizeof(unsigned long long)));
+        hipLaunchKernelGGL(bfs_edges_reached_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, (const int32_t*) dist.p, g->begin.p, V, qcount.p);
+        GMX_HIP(hipMemcpy(&edges_reached, qcount.p, sizeof(edges_reached), hipMemcpyDeviceToHost));
+    }
     hipEvent_t c0, c1;
     (void) hipEventCreate(&c0);
     (void) hipEventCreate(&c1);
@@ -306,6 +325,7 @@ extern "C" int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host,
         stats->d2h_ms = cms;
         stats->edges_examined = (int64_t) edges;
         stats->vertices_reached = reached;
+        stats->edges_reached = (int64_t) edges_reached;
     }
     return GMX_OK;
 }

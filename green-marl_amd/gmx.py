@@ -27,7 +27,7 @@ class GmxError(RuntimeError):
 class Stats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("reserved", C.c_int32), ("last_diff", C.c_double),
                 ("kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
-                ("edges_examined", C.c_int64), ("vertices_reached", C.c_int64)]
+                ("edges_examined", C.c_int64), ("vertices_reached", C.c_int64), ("edges_reached", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -15,9 +15,10 @@ for scale in scales:
             root = int(np.argmax(np.diff(begin)))
         for _ in range(2):
             dist, s = g.hop_dist(root)
-        print("RMAT-%d perm=%d root=%d hop_dist %.3f ms levels=%d reached=%d examined=%d  %.1f GTEPS(examined)" % (
-            scale, perm, root, s["kernel_ms"], s["iterations"], s["vertices_reached"], s["edges_examined"],
-            s["edges_examined"] / s["kernel_ms"] / 1e6), flush=True)
+        print("RMAT-%d perm=%d root=%d hop_dist %.3f ms levels=%d reached=%d examined=%d E_r=%d  %.1f GTEPS (E_r/t)  roofline(8E_r+12V_r)/t = %.0f GB/s" % (
+            scale, perm, root, s["kernel_ms"], s["iterations"], s["vertices_reached"], s["edges_examined"], s["edges_reached"],
+            s["edges_reached"] / s["kernel_ms"] / 1e6,
+            (8 * s["edges_reached"] + 12 * s["vertices_reached"]) / s["kernel_ms"] / 1e6), flush=True)
         if do_tc and perm == 0:
             t0 = time.time()
             T, s = g.triangle_counting()

@@ -106,6 +106,7 @@ typedef struct {
     double  d2h_ms;           /* property copy-out (Shoal copy-back analogue)    */
     int64_t edges_examined;   /* hop_dist: edges actually inspected              */
     int64_t vertices_reached; /* hop_dist                                         */
+    int64_t edges_reached;    /* hop_dist: out-edges of the reached vertices (Graph500 TEPS numerator) */
 } gmx_stats_t;
 
 /* ---- whole-kernel entries (what the three generated C++ functions call) ---- */
