@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scale", type=int, default=26)
+    ap.add_argument("--edge-factor", type=int, default=16, help="edges per vertex (22 at scale 26 ~ Twitter-2010's 1.47 G edges)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--options", type=int, default=-1, help="gmx_pr_create option bits (default: library default)")
     ap.add_argument("--cpu-scale", type=int, default=24)
@@ -89,7 +90,7 @@ def main():
 
     elem = 4 if args.dtype == "f32" else 8
     options = gmx.default_pr_options(1 << args.scale, world) if args.options < 0 else args.options
-    N, M = 1 << args.scale, 16 << args.scale
+    N, M = 1 << args.scale, args.edge_factor << args.scale
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -135,13 +136,14 @@ def main():
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "bench_traffic.json")))
-        traffic = tj.get("scale%d_%s_opt%d_gpus%d" % (args.scale, args.dtype, options, world))
+        if args.edge_factor == 16:
+            traffic = tj.get("scale%d_%s_opt%d_gpus%d" % (args.scale, args.dtype, options, world))
     except (OSError, ValueError):
         pass
 
     if rank == 0:
         out = {
-            "metric": "edges/s (GTEPS) per PageRank iter, RMAT-%d" % args.scale,
+            "metric": "edges/s (GTEPS) per PageRank iter, RMAT-%d" % args.scale + ("" if args.edge_factor == 16 else " x%d" % args.edge_factor),
             "value": gteps, "unit": "GTEPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",

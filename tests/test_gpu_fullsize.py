@@ -146,3 +146,51 @@ def test_triangle_counting_rmat24_symmetrized_runs(gmx):
     assert T <= int(gs.E) * int(np.diff(b).max())
     print("RMAT-24 symmetrised: E=%d T=%d %.1f ms" % (gs.E, T, st["kernel_ms"]))
     gs.free()
+
+
+def test_twitter_sized_graph_near_int32_limit(gmx):
+    """BASELINE configs[3] names Twitter-2010 (41.65 M vertices, 1 468 M edges); the dataset is not available,
+    so an RMAT-26 with edge factor 22 (67.1 M vertices, 1 476 M edges) stands in for its size: edge offsets
+    pass 2^30 and stay below the int32 limit of edge_t.  PageRank is checked on sampled rows, BFS by its
+    tree properties on the levels reached from the top hub."""
+    scale, ef = 26, 22
+    N, M = 1 << scale, ef << scale
+    assert (1 << 30) < M < (1 << 31)
+    g = gmx.Graph.rmat(N, M, 1997, 0.57, 0.19, 0.19, True)
+    assert g.E == M
+    begin, _, rb, rn = g.download()
+    assert int(begin[-1]) == M and int(rb[-1]) == M
+    outdeg = np.diff(begin).astype(np.float64)
+    root = int(np.argmax(outdeg))
+    del begin
+    ranks = []
+    for iters in (2, 3):
+        st = gmx.PageRankState(g, 4, 0, 1, gmx.default_pr_options(N, 1))
+        st.reset(0.85)
+        for _ in range(iters):
+            st.step()
+        ranks.append(st.download().astype(np.float64))
+        st.free()
+    prev, cur = ranks
+    rng = np.random.default_rng(1)
+    rows = np.unique(np.concatenate([rng.integers(0, N, 2000), np.argsort(np.diff(rb))[-32:]]))
+    worst = 0.0
+    for t in rows:
+        src = rn[rb[t]:rb[t + 1]]
+        want = 0.15 / N + 0.85 * np.sum(prev[src] / outdeg[src])
+        worst = max(worst, abs(cur[t] - want) / want)
+    assert worst < 2e-6, worst
+    dist, st = g.hop_dist(root)
+    assert dist[root] == 0 and st["vertices_reached"] == int((dist != INT_MAX).sum())
+    # every reached vertex other than the root has an in-neighbour one level closer (sampled)
+    reached = np.flatnonzero(dist != INT_MAX)
+    for t in rng.choice(reached, 3000, replace=False):
+        if t == root:
+            continue
+        assert dist[rn[rb[t]:rb[t + 1]]].min() == dist[t] - 1
+    # no unreached vertex has a reached in-neighbour (sampled)
+    unreached = np.flatnonzero(dist == INT_MAX)
+    for t in rng.choice(unreached, 3000, replace=False):
+        src = rn[rb[t]:rb[t + 1]]
+        assert len(src) == 0 or (dist[src] == INT_MAX).all()
+    g.free()
