@@ -409,6 +409,24 @@ struct prw_partial {
 //                           reduced and written out.
 // So the gathers of the next block and the index stream of the one after are always outstanding while a
 // block is being reduced.
+// How ids map to slots of the LDS tile.  Unsliced: slot = id.  Sliced: the tile holds, for every rank's
+// range (1 << rank_shift ids; rank_shift == 0: a single range), the per_rank hottest ids of the home slice;
+// an id's slice bits sit above the run offset and are squeezed out.
+struct prw_tile {
+    int lim;         // usable slots (0: no tile for this block)
+    int sliced;      // 0: slot = id
+    int sl_shift;    // log2(number of slices)
+    int rank_shift;  // log2(ids per rank range), 0 = one range
+    int per_rank;    // tile slots per rank range
+    __device__ __forceinline__ int slot(int32_t id) const {
+        if (!sliced) return id < lim ? id : -1;
+        const int local = rank_shift ? (id & ((1 << rank_shift) - 1)) : id;
+        const int q = ((local >> (PR_RUN_SHIFT + sl_shift)) << PR_RUN_SHIFT) | (local & ((1 << PR_RUN_SHIFT) - 1));
+        if (q >= per_rank) return -1;
+        return (rank_shift ? (id >> rank_shift) * per_rank : 0) + q;
+    }
+};
+
 template <typename S>
 struct prw_regs {
     int32_t rbv[PRW_ROWU];   // row starts
@@ -428,9 +446,8 @@ __device__ __forceinline__ void prw_load_idx(const int32_t* __restrict__ ridx, i
     }
 }
 
-// hot_lim == 0 disables the LDS tile; hot_shift: ids are mapped to tile slots of the home slice.
 template <typename S, typename OUT>
-__device__ __forceinline__ void prw_issue(const S* __restrict__ s_hot, int hot_lim, int hot_shift, int hot_sl_shift,
+__device__ __forceinline__ void prw_issue(const S* __restrict__ s_hot, const prw_tile tile,
                                           pr_blk b0, pr_blk b1,
                                           const int32_t* __restrict__ rb, const int32_t* __restrict__ outdeg,
                                           const S* __restrict__ rk_old, const S* __restrict__ contrib,
@@ -458,10 +475,8 @@ __device__ __forceinline__ void prw_issue(const S* __restrict__ s_hot, int hot_l
         g.vv[u] = (S) 0;
         const int32_t id = ix[u];
         if (id >= 0) {
-            // tile slot of an id of the home slice: drop the slice bits above the run offset
-            const int q = ((id >> (PR_RUN_SHIFT + hot_sl_shift)) << PR_RUN_SHIFT) | (id & ((1 << PR_RUN_SHIFT) - 1));
-            const int slot = hot_shift ? q : id;
-            if (slot < hot_lim) g.vv[u] = s_hot[slot];
+            const int slot = tile.lim > 0 ? tile.slot(id) : -1;
+            if (slot >= 0) g.vv[u] = s_hot[slot];
             else g.vv[u] = contrib[id];
         }
     }
@@ -610,7 +625,7 @@ pr_wave_kernel(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
         c0 = blk[kC];
         c1 = blk[kC + 1];
         prw_load_idx<NT>(ridx, c0.e, c1.e - c0.e, ixB);
-        prw_issue<S>(s_hot, HOT, 0, 0, c0, c1, rb, outdeg, rk, contrib, ixB, out, gC);
+        prw_issue<S>(s_hot, prw_tile{HOT, 0, 0, 0, HOT}, c0, c1, rb, outdeg, rk, contrib, ixB, out, gC);
     }
     if (kB < nblk) {
         b0 = blk[kB];
@@ -625,7 +640,7 @@ pr_wave_kernel(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
             a1 = blk[kA + 1];
             prw_load_idx<NT>(ridx, a0.e, a1.e - a0.e, ixA);
         }
-        if (kB < nblk) prw_issue<S>(s_hot, HOT, 0, 0, b0, b1, rb, outdeg, rk, contrib, ixB, out, gB);
+        if (kB < nblk) prw_issue<S>(s_hot, prw_tile{HOT, 0, 0, 0, HOT}, b0, b1, rb, outdeg, rk, contrib, ixB, out, gB);
         prw_consume<S>(w, kC, c0, c1, rows, gC, out, diff_acc);
         kC = kB;
         c0 = b0;
@@ -644,18 +659,24 @@ pr_wave_kernel(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
 // Sliced: waves on XCD x claim chunks of slice x % ns (stealing from the others when drained).
 template <typename S, int WAVES, int HOT, bool NT>
 __global__ void __launch_bounds__(WAVES * 64)
-pr_wave_sliced_kernel(pr_sliced_args a, int64_t rows, const S* __restrict__ contrib, int ns_shift) {
+pr_wave_sliced_kernel(pr_sliced_args a, int64_t ncontrib, const S* __restrict__ contrib, int ns_shift, int rank_shift, int nranks) {
     __shared__ prw_lds<S> lds[WAVES];
     __shared__ S s_hot[HOT > 0 ? HOT : 1];
     const int home = pr_xcc_id() % a.ns;
+    const int per_rank = HOT / (nranks > 0 ? nranks : 1);
     if (HOT > 0) {
-        // tile slot q <-> id ((q >> RUN) * ns + home) << RUN | (q & (RUN-1)): the hottest ids of the home slice
-        for (int q = threadIdx.x; q < HOT; q += WAVES * 64) {
-            const int64_t id = ((((int64_t) q >> PR_RUN_SHIFT) * a.ns + home) << PR_RUN_SHIFT) | (q & ((1 << PR_RUN_SHIFT) - 1));
-            s_hot[q] = id < rows ? contrib[id] : (S) 0;
+        // slot (r, q) <-> id (r << rank_shift) + (((q >> RUN) * ns + home) << RUN | (q & (RUN-1))):
+        // the per_rank hottest ids of the home slice inside every rank's range
+        for (int sidx = threadIdx.x; sidx < per_rank * nranks; sidx += WAVES * 64) {
+            const int r = sidx / per_rank, q = sidx - r * per_rank;
+            const int64_t id = ((int64_t) r << rank_shift) +
+                               (((((int64_t) q >> PR_RUN_SHIFT) * a.ns + home) << PR_RUN_SHIFT) | (q & ((1 << PR_RUN_SHIFT) - 1)));
+            s_hot[sidx] = id < ncontrib ? contrib[id] : (S) 0;
         }
         __syncthreads();
     }
+    const prw_tile tile_home{HOT > 0 ? per_rank * nranks : 0, 1, ns_shift, nranks > 1 ? rank_shift : 0, per_rank};
+    const prw_tile tile_none{0, 1, ns_shift, 0, 0};
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     prw_lds<S>* w = &lds[wv];
@@ -703,7 +724,7 @@ pr_wave_sliced_kernel(pr_sliced_args a, int64_t rows, const S* __restrict__ cont
         c0 = a.s[slC].blk[kC];
         c1 = a.s[slC].blk[kC + 1];
         prw_load_idx<NT>(a.s[slC].ridx, c0.e, c1.e - c0.e, ixB);
-        prw_issue<S>(s_hot, (HOT > 0 && slC == home) ? HOT : 0, 1, ns_shift, c0, c1, a.s[slC].rb,
+        prw_issue<S>(s_hot, slC == home ? tile_home : tile_none, c0, c1, a.s[slC].rb,
                      (const int32_t*) nullptr, (const S*) nullptr, contrib, ixB, policy(slC), gC);
         claim(kB, slB);
     } else {
@@ -726,7 +747,7 @@ pr_wave_sliced_kernel(pr_sliced_args a, int64_t rows, const S* __restrict__ cont
                 a1 = a.s[slA].blk[kA + 1];
                 prw_load_idx<NT>(a.s[slA].ridx, a0.e, a1.e - a0.e, ixA);
             }
-            prw_issue<S>(s_hot, (HOT > 0 && slB == home) ? HOT : 0, 1, ns_shift, b0, b1, a.s[slB].rb,
+            prw_issue<S>(s_hot, slB == home ? tile_home : tile_none, b0, b1, a.s[slB].rb,
                          (const int32_t*) nullptr, (const S*) nullptr, contrib, ixB, policy(slB), gB);
         }
         prw_consume<S>(w, (int64_t) kC, c0, c1, a.s[slC].crows, gC, policy(slC), unused);
@@ -918,7 +939,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
     }
     p->rows = p->ns > 0 ? p->slice : p->rows_real;
     p->exchange_count = p->slice;
-    p->hot = (options & GMX_PR_HOT_LDS) != 0 && relabel && nranks == 1;
+    p->hot = (options & GMX_PR_HOT_LDS) != 0 && relabel && (nranks == 1 || p->ns > 0);
     p->items = PRW_ITEMS;
 
     const int64_t V = g->V, E = g->E;
@@ -1202,17 +1223,23 @@ static void launch_sliced(gmx_pr* p, hipStream_t s) {
     if (total_blk > 0) {
         int ns_shift = 0;
         while ((1 << ns_shift) < p->ns) ns_shift++;
-        if (p->hot && (1 << ns_shift) == p->ns) {   // the tile's slot arithmetic needs a power-of-two slice count
+        // the tile's slot arithmetic is shifts only: power-of-two slice count, and with several ranks
+        // power-of-two range length and rank count (true for the RMAT benchmarks)
+        int rank_shift = 0;
+        while ((1LL << rank_shift) < p->slice) rank_shift++;
+        const bool pow2 = (1 << ns_shift) == p->ns &&
+                          (p->nranks == 1 || ((1LL << rank_shift) == p->slice && (p->nranks & (p->nranks - 1)) == 0));
+        if (p->hot && pow2) {
             constexpr int HOTQ = sizeof(S) == 4 ? 22528 : 7168;
             int64_t grid = p->persistent_grid;
             if (grid * 16 > total_blk) grid = (total_blk + 15) / 16;
-            hipLaunchKernelGGL((pr_wave_sliced_kernel<S, 16, HOTQ, true>), dim3((unsigned) grid), dim3(1024), 0, s, p->sl, p->rows,
-                               (const S*) p->contrib[p->cur].p, ns_shift);
+            hipLaunchKernelGGL((pr_wave_sliced_kernel<S, 16, HOTQ, true>), dim3((unsigned) grid), dim3(1024), 0, s, p->sl, p->Vpad,
+                               (const S*) p->contrib[p->cur].p, ns_shift, rank_shift, p->nranks);
         } else {
             int64_t grid = (int64_t) p->persistent_grid * 5;
             if (grid * 4 > total_blk) grid = (total_blk + 3) / 4;
-            hipLaunchKernelGGL((pr_wave_sliced_kernel<S, 4, 0, true>), dim3((unsigned) grid), dim3(256), 0, s, p->sl, p->rows,
-                               (const S*) p->contrib[p->cur].p, ns_shift);
+            hipLaunchKernelGGL((pr_wave_sliced_kernel<S, 4, 0, true>), dim3((unsigned) grid), dim3(256), 0, s, p->sl, p->Vpad,
+                               (const S*) p->contrib[p->cur].p, ns_shift, rank_shift, p->nranks);
         }
         hipLaunchKernelGGL(pr_sliced_fixup_kernel<S>, dim3((unsigned) ((maxblk + 255) / 256), p->ns), dim3(256), 0, s, p->sl, p->rows);
     }
@@ -1308,7 +1335,7 @@ extern "C" int gmx_pr_download(gmx_pr_t* p, void* rank_host) {
 // splitting the sources over the XCD L2s pays for its partial-sum pass (RMAT-24: 1.21 vs 1.53 ms).
 extern "C" uint32_t gmx_pr_default_options(int64_t V, int nranks) {
     uint32_t o = GMX_PR_RELABEL;
-    if (nranks == 1) o |= GMX_PR_HOT_LDS;
+    o |= GMX_PR_HOT_LDS;   // with several ranks the tile is only used by the sliced kernel
     if (V > (1LL << 21)) o |= GMX_PR_SLICED;
     return o;
 }

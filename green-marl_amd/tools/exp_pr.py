@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--bfs", type=int, default=1)
     ap.add_argument("--tc", type=int, default=0)
+    ap.add_argument("--nranks", type=int, default=1, help="time rank 0 of N ranks (no exchange: timing only)")
     args = ap.parse_args()
     print(gmx.device_info(), flush=True)
     for scale in [int(s) for s in args.scales.split(",")]:
@@ -32,7 +33,7 @@ def main():
             for elem in [int(s) for s in args.elems.split(",")]:
                 for opt in [int(s) for s in args.opts.split(",")]:
                     t0 = time.time()
-                    st = gmx.PageRankState(g, elem, 0, 1, opt)
+                    st = gmx.PageRankState(g, elem, 0, args.nranks, opt)
                     st.reset(0.85)
                     t1 = time.time()
                     for _ in range(2):

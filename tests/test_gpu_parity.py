@@ -195,7 +195,7 @@ def test_from_edges_matches_oracle(gmx):
     g.free()
 
 
-@pytest.mark.parametrize("nranks,options", [(2, 1), (4, 1), (3, 0), (2, 5), (3, 7)])
+@pytest.mark.parametrize("nranks,options", [(2, 1), (4, 1), (3, 0), (2, 5), (3, 7), (2, 7), (4, 7), (8, 7)])
 def test_pagerank_partitioned_ranks_in_one_process(gmx, nranks, options):
     """The C library's 1-D partition for N ranks, exercised on one GPU: every rank's state lives in
     this process and the all-gather is done with plain device copies (torch), then compared with
