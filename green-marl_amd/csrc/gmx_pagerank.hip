@@ -32,8 +32,9 @@ struct pr_blk { int32_t r, e; };  // merge-path start of a workgroup: local row 
 
 #define PR_MAX_SLICES 8
 #define PR_COMBINE_GRID 4096
+#define PR_MAX_CHUNKS 8
 #define PR_QUEUE_STRIDE 64       // work-queue counters live 256 bytes apart (one atomic unit each)
-#define PRW_QUEUE_CHUNK 16       // merge-path blocks (512 items) claimed per dequeue by a wave
+#define PRW_QUEUE_CHUNK 16       // merge-path blocks (512 items) claimed per dequeue by a wave (at most)
 #define PR_RUN_SHIFT 11         // sliced numbering: a slice owns runs of 2^11 consecutive ids (all L2 channels)
 
 // Per-slice device arrays of the XCD-sliced variant: slice s holds the in-edges whose SOURCE
@@ -51,6 +52,13 @@ struct pr_slice_desc {
                      // slice has no edge for keep the 0 they were initialised with (the graph is static)
     const int32_t* rowid;   // compact row -> local row: only rows with at least one edge in the slice are stored
     int64_t crows;          // number of compact rows
+    // per launch (row chunk): blocks [k_lo, k_hi) are reduced, openers [f_lo, f_hi) are fixed up
+    int64_t k_lo, k_hi, f_lo, f_hi;
+    int qchunk;   // blocks a wave claims per dequeue: <= PRW_QUEUE_CHUNK, smaller when the window is short
+    // static part of the schedule: wave w of the slice's st_waves waves takes the claims w, w + st_waves, ...
+    // for st_rounds rounds without touching the queue; the queue hands out the rest, from block k_lo + st_total
+    int st_rounds, st_waves;
+    int64_t st_total;
 };
 struct pr_sliced_args {
     pr_slice_desc s[PR_MAX_SLICES];
@@ -95,6 +103,11 @@ struct gmx_pr {
     dbuf<int32_t> sl_rb, sl_ridx, sl_rowid, sl_active;   // sl_active: local rows with in-edges
     dbuf<uint8_t> sl_is_active;
     int64_t sl_nactive = 0;
+    // row chunks of a step (1 = whole step at once); tables from pr_chunk_table_kernel
+    int nchunks = 1;
+    int64_t ch_row[PR_MAX_CHUNKS + 1];                       // boundary rows
+    int64_t ch_blk[PR_MAX_CHUNKS + 1][PR_MAX_SLICES];        // first block per slice
+    int64_t ch_act[PR_MAX_CHUNKS + 1];                       // first active-row entry
     dbuf<pr_blk> sl_blk;
     dbuf<double> sl_part_first, sl_part_last;
     dbuf<char> sl_partial;
@@ -664,17 +677,22 @@ pr_wave_sliced_kernel(pr_sliced_args a, int64_t ncontrib, const S* __restrict__ 
     __shared__ S s_hot[HOT > 0 ? HOT : 1];
     const int home = pr_xcc_id() % a.ns;
     const int per_rank = HOT / (nranks > 0 ? nranks : 1);
+    __shared__ int s_drained[PR_MAX_SLICES];   // slice queues this workgroup has seen empty
+    if (threadIdx.x < PR_MAX_SLICES) s_drained[threadIdx.x] = 0;
     if (HOT > 0) {
         // slot (r, q) <-> id (r << rank_shift) + (((q >> RUN) * ns + home) << RUN | (q & (RUN-1))):
         // the per_rank hottest ids of the home slice inside every rank's range
-        for (int sidx = threadIdx.x; sidx < per_rank * nranks; sidx += WAVES * 64) {
-            const int r = sidx / per_rank, q = sidx - r * per_rank;
-            const int64_t id = ((int64_t) r << rank_shift) +
-                               (((((int64_t) q >> PR_RUN_SHIFT) * a.ns + home) << PR_RUN_SHIFT) | (q & ((1 << PR_RUN_SHIFT) - 1)));
-            s_hot[sidx] = id < ncontrib ? contrib[id] : (S) 0;
+        for (int r = 0; r < nranks; r++) {
+            const int64_t id0 = (int64_t) r << rank_shift;
+            S* dst = s_hot + r * per_rank;
+#pragma unroll 4
+            for (int q = threadIdx.x; q < per_rank; q += WAVES * 64) {
+                const int64_t id = id0 + (((((int64_t) q >> PR_RUN_SHIFT) * a.ns + home) << PR_RUN_SHIFT) | (q & ((1 << PR_RUN_SHIFT) - 1)));
+                dst[q] = id < ncontrib ? contrib[id] : (S) 0;
+            }
         }
-        __syncthreads();
     }
+    __syncthreads();
     const prw_tile tile_home{HOT > 0 ? per_rank * nranks : 0, 1, ns_shift, nranks > 1 ? rank_shift : 0, per_rank};
     const prw_tile tile_none{0, 1, ns_shift, 0, 0};
     const int lane = threadIdx.x & 63;
@@ -682,27 +700,47 @@ pr_wave_sliced_kernel(pr_sliced_args a, int64_t ncontrib, const S* __restrict__ 
     prw_lds<S>* w = &lds[wv];
     double unused = 0.0;
 
-    // dequeue state (wave-uniform; lane 0 performs the atomic, the result is broadcast)
+    // Work distribution.  Merge-path blocks are equal work by construction, so most of a slice's window is
+    // dealt out statically (interleaved over the waves the launch gives that slice); only the tail goes
+    // through the per-slice queue, which also lets drained waves steal from other slices.  The queue
+    // counters are the scarce resource: atomics on one address retire at ~90 per microsecond, device wide.
+    // (wave-uniform state; lane 0 performs the atomic, the result is broadcast)
     long long k_next = 0, k_end = 0;
     int cur = home, first_try = 0;
+    // the static deal is keyed by blockIdx alone (unique by construction); workgroups go round-robin over
+    // the 8 XCDs, so this is the home slice
+    const int st_slice = (int) ((blockIdx.x & 7) % a.ns);
+    const int st_idx = (int) (((blockIdx.x >> 3) * (8 / a.ns) + (blockIdx.x & 7) / a.ns) * WAVES + wv);
+    int st_round = 0;
     auto claim = [&](long long& k_out, int& sl_out) {
         long long k = -1;
         if (k_next < k_end) k = k_next++;
-        else {
+        else if (st_round < a.s[st_slice].st_rounds) {
+            const pr_slice_desc& sd = a.s[st_slice];
+            k = sd.k_lo + ((long long) st_round * sd.st_waves + st_idx) * sd.qchunk;
+            st_round++;
+            k_next = k + 1;
+            k_end = k + sd.qchunk;   // static claims are whole and inside the window
+            cur = st_slice;
+        } else {
             for (int t = first_try; t < a.ns; t++) {
                 cur = (home + t) % a.ns;
-                const long long nb = a.s[cur].nblk;
+                first_try = t + 1;
+                // a queue some wave of this workgroup has seen empty costs an LDS read, not another atomic
+                if (*(volatile int*) &s_drained[cur]) continue;
+                const long long nb = a.s[cur].k_hi;
+                const int qc = a.s[cur].qchunk;
                 unsigned int kk0 = 0;
-                if (lane == 0) kk0 = atomicAdd(&a.queue[cur * PR_QUEUE_STRIDE], (unsigned int) PRW_QUEUE_CHUNK);
-                const long long kk = (long long) (unsigned int) __builtin_amdgcn_readfirstlane((int) kk0);
+                if (lane == 0) kk0 = atomicAdd(&a.queue[cur * PR_QUEUE_STRIDE], (unsigned int) qc);
+                const long long kk = a.s[cur].k_lo + a.s[cur].st_total + (long long) (unsigned int) __builtin_amdgcn_readfirstlane((int) kk0);
                 if (kk < nb) {
                     k = kk;
                     k_next = kk + 1;
-                    k_end = kk + PRW_QUEUE_CHUNK < nb ? kk + PRW_QUEUE_CHUNK : nb;
+                    k_end = kk + qc < nb ? kk + qc : nb;
                     first_try = t;
                     break;
                 }
-                first_try = t + 1;
+                if (lane == 0) *(volatile int*) &s_drained[cur] = 1;
             }
         }
         k_out = k;
@@ -766,23 +804,53 @@ pr_wave_sliced_kernel(pr_sliced_args a, int64_t ncontrib, const S* __restrict__ 
 }
 
 // Rows that span workgroups: the workgroup that OPENED row r (r == blk[k+1].r, rb[r] in
-// [e0,e1)) left part_last[k]; every later workgroup touching r left part_first[k'].
+// [e0,e1)) left part_last[k]; every later workgroup touching r (blk[k'].r == r) left part_first[k'].
+// One thread per opener adds the first few pieces itself; a row that goes on (a hub: thousands of blocks)
+// is summed by the whole wave, lanes striding over part_first in a fixed order.
+#define PR_FIX_SERIAL 16
 template <typename S, typename OUT>
 __device__ __forceinline__ void pr_fixup_one(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
-                                             const int32_t* __restrict__ rb, int64_t k, const OUT& out, double& diff_acc) {
-    const pr_blk b0 = blk[k], b1 = blk[k + 1];
-    const int64_t r = b1.r;
-    if (r < rows) {
-        const int32_t rs = rb[r];
-        if (rs >= b0.e && rs < b1.e) {
-            double total = out.part_last[k];
-            for (int64_t kk = k + 1; kk < nblk; kk++) {
+                                             const int32_t* __restrict__ rb, int64_t k, bool valid, const OUT& out, double& diff_acc) {
+    const int lane = threadIdx.x & 63;
+    bool opener = false, pending = false;
+    long long r = 0, kk = 0;
+    double total = 0.0;
+    if (valid) {
+        const pr_blk b0 = blk[k], b1 = blk[k + 1];
+        r = b1.r;
+        if (r < rows) {
+            const int32_t rs = rb[r];
+            opener = rs >= b0.e && rs < b1.e;
+        }
+        if (opener) {
+            total = out.part_last[k];
+            pending = true;
+            for (kk = k + 1; kk < nblk && kk <= k + PR_FIX_SERIAL; kk++) {
                 total += out.part_first[kk];
-                if (blk[kk + 1].r > r) break;
+                if (blk[kk + 1].r > r) {
+                    pending = false;
+                    break;
+                }
             }
-            out.row(r, total, diff_acc);
+            if (kk >= nblk) pending = false;
         }
     }
+    unsigned long long m = __ballot(pending);
+    while (m) {   // whole wave: blocks kk, kk+1, ... of lane src's row, 64 per round, until one starts in a later row
+        const int src = __ffsll((long long) m) - 1;
+        m &= m - 1;
+        const long long r0 = __shfl(r, src, 64);
+        long long q = __shfl(kk, src, 64) + lane;
+        double t = 0.0;
+        for (;; q += 64) {
+            const bool in = q < nblk && blk[q].r == r0;
+            if (in) t += out.part_first[q];
+            if (__ballot(in) != ~0ull) break;
+        }
+        t = __shfl(wave_sum(t), 0, 64);
+        if (lane == src) total += t;
+    }
+    if (opener) out.row(r, total, diff_acc);
 }
 
 template <typename S>
@@ -795,10 +863,8 @@ pr_fixup_kernel(const pr_blk* __restrict__ blk, int64_t nblk, int64_t rows,
     __shared__ double s_red[256 / 64];
     int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     double diff_acc = 0.0;
-    if (k < nblk) {
-        out_final<S> out{rk, outdeg, contrib_next_owned, base, d, part_first, part_last};
-        pr_fixup_one<S>(blk, nblk, rows, rb, k, out, diff_acc);
-    }
+    out_final<S> out{rk, outdeg, contrib_next_owned, base, d, part_first, part_last};
+    pr_fixup_one<S>(blk, nblk, rows, rb, k, k < nblk, out, diff_acc);
     if (k < n_main) diff_acc += diff_main[k];   // fold in the main kernel's partials (fixed order)
     pr_block_diff<256>(diff_acc, s_red, diff_out + blockIdx.x);
 }
@@ -807,11 +873,10 @@ template <typename S>
 __global__ void pr_sliced_fixup_kernel(pr_sliced_args a, int64_t rows) {
     const int sl = blockIdx.y;
     const pr_slice_desc& sd = a.s[sl];
-    int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= sd.nblk) return;
+    int64_t k = sd.f_lo + (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     double unused = 0.0;
     out_partial<S> out{(S*) sd.partial, sd.rowid, sd.part_first, sd.part_last};
-    pr_fixup_one<S>(sd.blk, sd.nblk, sd.crows, sd.rb, k, out, unused);
+    pr_fixup_one<S>(sd.blk, sd.nblk, sd.crows, sd.rb, k, k < sd.f_hi, out, unused);
 }
 
 // Sum the slices in fixed order and apply the PageRank update.  Only rows that have in-edges are
@@ -835,23 +900,62 @@ pr_combine_kernel(pr_sliced_args a, const int32_t* __restrict__ active, int64_t 
     pr_block_diff<256>(diff_acc, s_red, diff_part + blockIdx.x);
 }
 
-// First sweep after a reset: rows with no in-edges.  Writes their (from now on constant) contribution
-// into BOTH replicas, since later sweeps only rewrite the active rows of the replica they produce.
+// First sweep after a reset: rows with no in-edges get their (from now on constant) rank and contribution.
+// Later sweeps only rewrite the active rows of the replica they produce, so the value has to end up in BOTH
+// replicas: each row chunk writes the replica being produced (its piece may travel right away), and
+// pr_inactive_copy_kernel patches the replica being read once the whole sweep has finished reading it.
 template <typename S>
 __global__ void __launch_bounds__(256)
-pr_inactive_first_kernel(const uint8_t* __restrict__ is_active, int64_t rows, const int32_t* __restrict__ outdeg,
-                         S* __restrict__ rk, S* __restrict__ contrib_cur_owned, S* __restrict__ contrib_next_owned,
+pr_inactive_first_kernel(const uint8_t* __restrict__ is_active, int64_t r_lo, int64_t r_hi, const int32_t* __restrict__ outdeg,
+                         S* __restrict__ rk, S* __restrict__ contrib_next_owned,
                          double base, double d, double* __restrict__ diff_part) {
     __shared__ double s_red[256 / 64];
     double diff_acc = 0.0;
-    int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t r = r_lo + (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
-    for (; r < rows; r += stride) {
+    for (; r < r_hi; r += stride) {
         if (is_active[r]) continue;
         pr_finalize<S>(r, 0.0, base, d, rk, outdeg, contrib_next_owned, diff_acc);
-        contrib_cur_owned[r] = contrib_next_owned[r];
     }
     pr_block_diff<256>(diff_acc, s_red, diff_part + blockIdx.x);
+}
+
+template <typename S>
+__global__ void __launch_bounds__(256)
+pr_inactive_copy_kernel(const uint8_t* __restrict__ is_active, int64_t rows, S* __restrict__ contrib_cur_owned,
+                        const S* __restrict__ contrib_next_owned) {
+    int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; r < rows; r += stride)
+        if (!is_active[r]) contrib_cur_owned[r] = contrib_next_owned[r];
+}
+
+// Row chunks: for boundary row B, per slice the merge-path block that holds the first path item of the first
+// compact row >= B (rows >= B lie in that block and later ones, rows < B in that block and earlier ones),
+// and the first entry of active[] that is >= B.  out[(ns + 1) * c + sl], last column = active.
+__global__ void pr_chunk_table_kernel(pr_sliced_args a, const int32_t* __restrict__ active, int64_t nactive,
+                                      const int64_t* __restrict__ bounds, int nb, int items, int64_t* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb * (a.ns + 1)) return;
+    const int c = t / (a.ns + 1), sl = t % (a.ns + 1);
+    const int64_t B = bounds[c];
+    if (sl == a.ns) {
+        int64_t lo = 0, hi = nactive;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (active[mid] < B) lo = mid + 1; else hi = mid;
+        }
+        out[t] = lo;
+        return;
+    }
+    const pr_slice_desc& sd = a.s[sl];
+    int64_t lo = 0, hi = sd.crows;
+    while (lo < hi) {   // first compact row whose local row >= B
+        int64_t mid = (lo + hi) >> 1;
+        if (sd.rowid[mid] < B) lo = mid + 1; else hi = mid;
+    }
+    // path position of a row's first item = edges before it + row ends before it
+    out[t] = lo < sd.crows ? ((int64_t) sd.rb[lo] + lo) / items : sd.nblk;
 }
 
 __global__ void pr_mark_active_kernel(const uint64_t* __restrict__ keys, int64_t n, int64_t row_lo, uint8_t* __restrict__ is_active) {
@@ -898,6 +1002,8 @@ __global__ void pr_unpermute_kernel(int64_t rows, const int32_t* __restrict__ in
 }
 
 // ------------------------------------------------------------------ plan
+static int pr_build_chunks(gmx_pr* p, int C);
+
 extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nranks, uint32_t options, gmx_pr_t** out) {
     GMX_REQUIRE(out, "out is NULL");
     *out = nullptr;
@@ -1135,7 +1241,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
         }
         // merge-path blocks
         int64_t total = p->rows + p->El;
-        p->nblk = p->ns > 0 ? 2 * PR_COMBINE_GRID : (total + p->items - 1) / p->items;   // sliced: diff partials of the combine (+ first-sweep) grid
+        p->nblk = p->ns > 0 ? 2 * PR_MAX_CHUNKS * PR_COMBINE_GRID : (total + p->items - 1) / p->items;   // sliced: diff partials of the combine (+ first-sweep) grids of every chunk
         if ((st = p->blk.alloc((size_t) p->nblk + 1))) break;
         if (p->ns == 0)
             hipLaunchKernelGGL(pr_blocks_kernel, dim3(grid_for(p->nblk + 1, 256, 1 << 30)), dim3(256), 0, s,
@@ -1154,6 +1260,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
         (void) hipGetDevice(&dev);
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { gmx_set_error("hipGetDeviceProperties failed"); st = GMX_ERR_HIP; break; }
         p->persistent_grid = prop.multiProcessorCount;
+        if (p->ns > 0 && (st = pr_build_chunks(p, 1))) break;
     } while (0);
     if (st != GMX_OK) { delete p; return st; }
     *out = p;
@@ -1208,17 +1315,71 @@ static void launch_wave(gmx_pr* p, hipStream_t s) {
     hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) diff_fix, fix_blocks, p->diff.p);
 }
 
-// Sliced step: per-slice row sums, fix-up per slice, then the combine pass that applies the update.
+// Row-chunk boundaries over the exchanged prefix [0, exchange_count) of a rank's range, the same on every rank.
+// Rows are in hotness order, so almost all edges belong to the first rows: chunk j covers the fractions
+// [4^-(C-j), 4^-(C-j-1)) of the prefix (chunk 0 starts at 0), rounded to whole runs.  A step walks the chunks
+// from the LAST (many rows, few edges -- most of the bytes to exchange are ready almost at once) to the first
+// (the hubs: most of the sweep time, which then hides the exchange of everything else).
+static int64_t pr_chunk_bound(const gmx_pr* p, int j) {
+    const int C = p->nchunks;
+    if (j <= 0) return 0;
+    if (j >= C) return p->exchange_count;
+    const int64_t unit = (int64_t) 1 << PR_RUN_SHIFT;
+    int64_t b = p->exchange_count >> (2 * (C - j));
+    b = (b + unit - 1) / unit * unit;
+    return b < p->exchange_count ? b : p->exchange_count;
+}
+
+static int pr_build_chunks(gmx_pr* p, int C) {
+    if (C < 1) C = 1;
+    if (C > PR_MAX_CHUNKS) C = PR_MAX_CHUNKS;
+    p->nchunks = C;
+    for (int j = 0; j <= C; j++) {
+        const int64_t b = pr_chunk_bound(p, j);
+        p->ch_row[j] = (j == C || b > p->rows) ? p->rows : b;   // rows past the prefix ride with the last chunk
+    }
+    dbuf<int64_t> bounds, table;
+    const int n = (C + 1) * (p->ns + 1);
+    GMX_CHECK(bounds.alloc((size_t) C + 1));
+    GMX_CHECK(table.alloc((size_t) n));
+    GMX_HIP(hipMemcpy(bounds.p, p->ch_row, sizeof(int64_t) * (C + 1), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(pr_chunk_table_kernel, dim3(1), dim3(128), 0, 0, p->sl, (const int32_t*) p->sl_active.p, p->sl_nactive,
+                       (const int64_t*) bounds.p, C + 1, p->items, table.p);
+    std::vector<int64_t> h((size_t) n);
+    GMX_HIP(hipMemcpy(h.data(), table.p, sizeof(int64_t) * n, hipMemcpyDeviceToHost));
+    for (int j = 0; j <= C; j++) {
+        for (int q = 0; q < p->ns; q++) p->ch_blk[j][q] = (j == C) ? p->sl.s[q].nblk : (j == 0 ? 0 : h[(size_t) j * (p->ns + 1) + q]);
+        p->ch_act[j] = (j == C) ? p->sl_nactive : (j == 0 ? 0 : h[(size_t) j * (p->ns + 1) + p->ns]);
+    }
+    if (getenv("GMX_PR_DEBUG"))
+        for (int j = 0; j <= C; j++) {
+            fprintf(stderr, "gmx pr chunk %d: row %lld active %lld blocks", j, (long long) p->ch_row[j], (long long) p->ch_act[j]);
+            for (int q = 0; q < p->ns; q++) fprintf(stderr, " %lld", (long long) p->ch_blk[j][q]);
+            fprintf(stderr, "\n");
+        }
+    return GMX_OK;
+}
+
+// Sliced step, one row chunk (c counts in processing order, i.e. from the last row chunk to the first):
+// per-slice row sums of the chunk's blocks, fix-up of the rows that begin in them, then the combine pass over
+// the chunk's rows.  The block holding a chunk boundary belongs to the LATER row chunk, which runs first, so
+// everything a row needs has been computed when its chunk is combined.  The last call closes the step.
 template <typename S>
-static void launch_sliced(gmx_pr* p, hipStream_t s) {
+static void launch_sliced_chunk(gmx_pr* p, int c, hipStream_t s) {
     const double N = (double) p->V;
     const double base = (1 - p->d) / N;
+    const int C = p->nchunks;
+    const int j = C - 1 - c;
     S* next_owned = (S*) p->contrib[1 - p->cur].p + p->row_lo;
     (void) hipMemsetAsync(p->sl_queue.p, 0, sizeof(unsigned int) * PR_MAX_SLICES * PR_QUEUE_STRIDE, s);
-    int64_t maxblk = 0, total_blk = 0;
+    pr_sliced_args a = p->sl;
+    int64_t maxfix = 0, total_blk = 0;
     for (int q = 0; q < p->ns; q++) {
-        maxblk = p->sl.s[q].nblk > maxblk ? p->sl.s[q].nblk : maxblk;
-        total_blk += p->sl.s[q].nblk;
+        pr_slice_desc& sd = a.s[q];
+        sd.k_lo = sd.f_lo = p->ch_blk[j][q];
+        sd.k_hi = sd.f_hi = p->ch_blk[j + 1][q];
+        if (sd.f_hi - sd.f_lo > maxfix) maxfix = sd.f_hi - sd.f_lo;
+        total_blk += sd.k_hi - sd.k_lo;
     }
     if (total_blk > 0) {
         int ns_shift = 0;
@@ -1229,40 +1390,101 @@ static void launch_sliced(gmx_pr* p, hipStream_t s) {
         while ((1LL << rank_shift) < p->slice) rank_shift++;
         const bool pow2 = (1 << ns_shift) == p->ns &&
                           (p->nranks == 1 || ((1LL << rank_shift) == p->slice && (p->nranks & (p->nranks - 1)) == 0));
+        // claim size: about 8 dequeues per wave over the window, so the tail of a short window (many ranks,
+        // row chunks) stays a small fraction of it
+        auto set_qchunk = [&](int64_t grid, int waves_per_wg) {
+            const int64_t waves = grid * waves_per_wg;
+            const int64_t per_slice = waves / p->ns > 0 ? waves / p->ns : 1;
+            // static deal: needs every slice to own the same number of whole workgroups per XCD
+            const bool can_static = p->ns <= 8 && 8 % p->ns == 0 && grid % 8 == 0 && !getenv("GMX_PR_NO_STATIC");
+            for (int q = 0; q < p->ns; q++) {
+                pr_slice_desc& sd = a.s[q];
+                const int64_t win = sd.k_hi - sd.k_lo;
+                int64_t qc = win / (per_slice * 8);
+                sd.qchunk = (int) (qc < 1 ? 1 : qc > PRW_QUEUE_CHUNK ? PRW_QUEUE_CHUNK : qc);
+                sd.st_waves = (int) per_slice;
+                sd.st_rounds = 0;
+                if (can_static) sd.st_rounds = (int) (win * 7 / 8 / (per_slice * sd.qchunk));   // 7/8 static, the tail dynamic
+                sd.st_total = (int64_t) sd.st_rounds * per_slice * sd.qchunk;
+            }
+        };
         if (p->hot && pow2) {
             constexpr int HOTQ = sizeof(S) == 4 ? 22528 : 7168;
             int64_t grid = p->persistent_grid;
             if (grid * 16 > total_blk) grid = (total_blk + 15) / 16;
-            hipLaunchKernelGGL((pr_wave_sliced_kernel<S, 16, HOTQ, true>), dim3((unsigned) grid), dim3(1024), 0, s, p->sl, p->Vpad,
+            if (grid >= 8) grid -= grid % 8;
+            set_qchunk(grid, 16);
+            hipLaunchKernelGGL((pr_wave_sliced_kernel<S, 16, HOTQ, true>), dim3((unsigned) grid), dim3(1024), 0, s, a, p->Vpad,
                                (const S*) p->contrib[p->cur].p, ns_shift, rank_shift, p->nranks);
         } else {
             int64_t grid = (int64_t) p->persistent_grid * 5;
             if (grid * 4 > total_blk) grid = (total_blk + 3) / 4;
-            hipLaunchKernelGGL((pr_wave_sliced_kernel<S, 4, 0, true>), dim3((unsigned) grid), dim3(256), 0, s, p->sl, p->Vpad,
+            if (grid >= 8) grid -= grid % 8;
+            set_qchunk(grid, 4);
+            hipLaunchKernelGGL((pr_wave_sliced_kernel<S, 4, 0, true>), dim3((unsigned) grid), dim3(256), 0, s, a, p->Vpad,
                                (const S*) p->contrib[p->cur].p, ns_shift, rank_shift, p->nranks);
         }
-        hipLaunchKernelGGL(pr_sliced_fixup_kernel<S>, dim3((unsigned) ((maxblk + 255) / 256), p->ns), dim3(256), 0, s, p->sl, p->rows);
     }
-    hipLaunchKernelGGL(pr_combine_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, p->sl, (const int32_t*) p->sl_active.p, p->sl_nactive,
-                       p->outdeg.p, (S*) p->rk.p, next_owned, base, p->d, p->diff_part.p);
-    int64_t nparts = PR_COMBINE_GRID;
+    if (maxfix > 0)
+        hipLaunchKernelGGL(pr_sliced_fixup_kernel<S>, dim3((unsigned) ((maxfix + 255) / 256), p->ns), dim3(256), 0, s, a, p->rows);
+    double* dpart = p->diff_part.p + (int64_t) c * 2 * PR_COMBINE_GRID;
+    hipLaunchKernelGGL(pr_combine_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, a, (const int32_t*) p->sl_active.p + p->ch_act[j],
+                       p->ch_act[j + 1] - p->ch_act[j], p->outdeg.p, (S*) p->rk.p, next_owned, base, p->d, dpart);
     if (p->cnt == 0) {   // first sweep after a reset: settle the rows without in-edges once
-        S* cur_owned = (S*) p->contrib[p->cur].p + p->row_lo;
-        hipLaunchKernelGGL(pr_inactive_first_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, (const uint8_t*) p->sl_is_active.p, p->rows,
-                           p->outdeg.p, (S*) p->rk.p, cur_owned, next_owned, base, p->d, p->diff_part.p + PR_COMBINE_GRID);
-        nparts = 2 * PR_COMBINE_GRID;
-    }
-    hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) p->diff_part.p, nparts, p->diff.p);
+        hipLaunchKernelGGL(pr_inactive_first_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, (const uint8_t*) p->sl_is_active.p,
+                           p->ch_row[j], p->ch_row[j + 1], p->outdeg.p, (S*) p->rk.p, next_owned, base, p->d,
+                           dpart + PR_COMBINE_GRID);
+        if (c == C - 1)
+            hipLaunchKernelGGL(pr_inactive_copy_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, (const uint8_t*) p->sl_is_active.p,
+                               p->rows, (S*) p->contrib[p->cur].p + p->row_lo, (const S*) next_owned);
+    } else (void) hipMemsetAsync(dpart + PR_COMBINE_GRID, 0, sizeof(double) * PR_COMBINE_GRID, s);
+    if (c == C - 1)
+        hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) p->diff_part.p,
+                           (int64_t) C * 2 * PR_COMBINE_GRID, p->diff.p);
 }
 
-extern "C" int gmx_pr_step(gmx_pr_t* p, void* stream) {
+extern "C" int gmx_pr_set_chunks(gmx_pr_t* p, int chunks) {
     GMX_REQUIRE(p, "pr is NULL");
+    GMX_REQUIRE(chunks >= 1 && chunks <= PR_MAX_CHUNKS, "chunks must be in 1..%d", PR_MAX_CHUNKS);
+    if (p->ns == 0) {   // the unsliced step is one piece
+        p->nchunks = 1;
+        return GMX_OK;
+    }
+    return pr_build_chunks(p, chunks);
+}
+
+extern "C" int gmx_pr_num_chunks(gmx_pr_t* p, int* chunks) {
+    GMX_REQUIRE(p && chunks, "NULL argument");
+    *chunks = p->nchunks;
+    return GMX_OK;
+}
+
+extern "C" int gmx_pr_chunk_range(gmx_pr_t* p, int chunk, int64_t* offset, int64_t* count) {
+    GMX_REQUIRE(p && offset && count, "NULL argument");
+    GMX_REQUIRE(chunk >= 0 && chunk < p->nchunks, "chunk %d out of range", chunk);
+    if (p->ns == 0) {
+        *offset = 0;
+        *count = p->exchange_count;
+        return GMX_OK;
+    }
+    // the same on every rank (boundaries depend on exchange_count and the chunk count only): entries past a
+    // short last rank's rows are padding that stays 0.  Chunks are numbered in processing order.
+    const int j = p->nchunks - 1 - chunk;
+    const int64_t lo = pr_chunk_bound(p, j), hi = pr_chunk_bound(p, j + 1);
+    *offset = lo;
+    *count = hi - lo;
+    return GMX_OK;
+}
+
+extern "C" int gmx_pr_step_chunk(gmx_pr_t* p, int chunk, void* stream) {
+    GMX_REQUIRE(p, "pr is NULL");
+    GMX_REQUIRE(chunk >= 0 && chunk < p->nchunks, "chunk %d out of range", chunk);
     hipStream_t s = (hipStream_t) stream;
-    pr_ev_begin(p, s);   // one "launch" of the roofline = all kernels of one step
+    if (chunk == 0) pr_ev_begin(p, s);   // one "launch" of the roofline = all kernels of one step
     if (p->ns > 0) {
         if (p->rows > 0) {
-            if (p->elem == 4) launch_sliced<float>(p, s);
-            else launch_sliced<double>(p, s);
+            if (p->elem == 4) launch_sliced_chunk<float>(p, chunk, s);
+            else launch_sliced_chunk<double>(p, chunk, s);
         }
     } else if (p->nblk > 0) {
         if (p->hot) {
@@ -1273,10 +1495,26 @@ extern "C" int gmx_pr_step(gmx_pr_t* p, void* stream) {
             else launch_wave<double, 4, 0>(p, s);
         }
     }
-    pr_ev_end(p, s);
     GMX_HIP(hipGetLastError());
-    p->cur = 1 - p->cur;
-    p->cnt++;
+    if (chunk == p->nchunks - 1) {
+        pr_ev_end(p, s);
+        p->cur = 1 - p->cur;
+        p->cnt++;
+    }
+    return GMX_OK;
+}
+
+extern "C" int gmx_pr_step(gmx_pr_t* p, void* stream) {
+    GMX_REQUIRE(p, "pr is NULL");
+    for (int c = 0; c < p->nchunks; c++) GMX_CHECK(gmx_pr_step_chunk(p, c, stream));
+    return GMX_OK;
+}
+
+// Device pointer of the replica the CURRENT step writes (the exchange of a finished chunk targets it).
+extern "C" int gmx_pr_contrib_next_full(gmx_pr_t* p, void** dev_ptr, int64_t* count) {
+    GMX_REQUIRE(p && dev_ptr && count, "NULL argument");
+    *dev_ptr = p->contrib[1 - p->cur].p;
+    *count = p->Vpad;
     return GMX_OK;
 }
 

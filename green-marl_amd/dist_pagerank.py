@@ -10,6 +10,9 @@ with the sweep split over ranks:
     xGMI topology every GPU sends V*s/G bytes to each peer directly, which is the
     bandwidth-optimal form of the north star's "all-reduce of the rank vector" (owned range
     filled, rest zero, sum = concatenation);
+  * with C > 1 row chunks (engine.set_chunks) the sweep is enqueued chunk by chunk and the all-gather of
+    chunk c's freshly written piece runs (async, on the process group's own stream) while chunk c+1 is
+    computed -- the exchange hides behind the sweep instead of following it;
   * `diff` is a 1-element fp64 all-reduce(SUM) -- the ATOMIC_ADD<double>(&diff, diff_prv) of the
     emitted code with ranks in place of threads.
 
@@ -43,6 +46,21 @@ class GmxEngine:
 
     def step(self):
         self.state.step(None)   # default stream == torch's current stream: ordered with the collectives
+
+    def set_chunks(self, chunks):
+        return self.state.set_chunks(chunks)
+
+    def num_chunks(self):
+        return self.state.num_chunks()
+
+    def chunk_range(self, chunk):
+        return self.state.chunk_range(chunk)
+
+    def step_chunk(self, chunk):
+        self.state.step_chunk(chunk, None)
+
+    def contrib_next_full(self):
+        return self._wrap(self.state.contrib_next_full())
 
     def contrib_slice(self):
         return self._wrap(self.state.contrib_slice())
@@ -94,10 +112,33 @@ class DistPageRank:
         self.cnt = 0
         self._exchange()
 
+    def _step_chunked(self, chunks):
+        """Sweep chunk c+1 while chunk c's new contributions travel."""
+        eng = self.engine
+        n = eng.contrib_slice().numel()
+        nxt = eng.contrib_next_full()          # the replica this step writes
+        rank = dist.get_rank(self.group)
+        pending = []
+        for c in range(chunks):
+            eng.step_chunk(c)
+            off, cnt = eng.chunk_range(c)
+            if cnt == 0:
+                continue
+            parts = [nxt[r * n + off:r * n + off + cnt] for r in range(self.world)]
+            # async: the collective is ordered after the kernels enqueued so far and runs on the process
+            # group's stream; this stream goes on with the next chunk
+            pending.append(dist.all_gather(parts, parts[rank].clone(), group=self.group, async_op=True))
+        for w in pending:
+            w.wait()                           # the next sweep reads the whole replica
+
     def step(self):
         """One PageRank iteration of the whole job (local sweep + exchange); asynchronous on GPU."""
-        self.engine.step()
-        self._exchange()
+        chunks = self.engine.num_chunks() if hasattr(self.engine, "num_chunks") else 1
+        if chunks > 1 and (self.world > 1 or self.always_exchange):
+            self._step_chunked(chunks)
+        else:
+            self.engine.step()
+            self._exchange()
         self.cnt += 1
 
     def diff(self):

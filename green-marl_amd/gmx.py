@@ -46,6 +46,7 @@ EXPORTS = [
     "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_triangle_counting",
     "gmx_pr_create", "gmx_pr_free", "gmx_pr_reset", "gmx_pr_step", "gmx_pr_contrib_slice",
     "gmx_pr_contrib_full", "gmx_pr_exchange_count", "gmx_pr_diff_ptr", "gmx_pr_diff", "gmx_pr_download", "gmx_pr_work",
+    "gmx_pr_set_chunks", "gmx_pr_num_chunks", "gmx_pr_chunk_range", "gmx_pr_step_chunk", "gmx_pr_contrib_next_full",
     "gmx_pr_timing", "gmx_pr_kernel_time", "gmx_pr_kernel_name", "gmx_pr_default_options",
 ]
 
@@ -58,6 +59,13 @@ def lib():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise GmxError("libgmx.so not built: run `make -C green-marl_amd lib` (or __graft_entry__.build())")
+        # PyTorch-ROCm bundles its own HIP runtime (same soname as /opt/rocm's).  Whichever is loaded first
+        # serves the whole process; torch must be that one, or its own device discovery fails later
+        # ("No HIP GPUs are available") when the multi-GPU driver wraps these buffers in tensors.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
         L.gmx_last_error.restype = C.c_char_p
@@ -86,6 +94,11 @@ def lib():
         L.gmx_pr_contrib_slice.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
         L.gmx_pr_contrib_full.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
         L.gmx_pr_diff_ptr.argtypes = [vp, C.POINTER(vp)]
+        L.gmx_pr_set_chunks.argtypes = [vp, C.c_int]
+        L.gmx_pr_num_chunks.argtypes = [vp, C.POINTER(C.c_int)]
+        L.gmx_pr_chunk_range.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(i64)]
+        L.gmx_pr_step_chunk.argtypes = [vp, C.c_int, vp]
+        L.gmx_pr_contrib_next_full.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
         L.gmx_pr_exchange_count.argtypes = [vp, C.POINTER(i64)]
         L.gmx_pr_diff.argtypes = [vp, vp, C.POINTER(C.c_double)]
         L.gmx_pr_download.argtypes = [vp, vp]
@@ -265,6 +278,28 @@ class PageRankState:
 
     def step(self, stream=None):
         _ck(lib().gmx_pr_step(self._h, stream))
+
+    def set_chunks(self, chunks):
+        _ck(lib().gmx_pr_set_chunks(self._h, int(chunks)))
+        return self.num_chunks()
+
+    def num_chunks(self):
+        n = C.c_int(0)
+        _ck(lib().gmx_pr_num_chunks(self._h, C.byref(n)))
+        return n.value
+
+    def chunk_range(self, chunk):
+        off, cnt = C.c_int64(0), C.c_int64(0)
+        _ck(lib().gmx_pr_chunk_range(self._h, chunk, C.byref(off), C.byref(cnt)))
+        return off.value, cnt.value
+
+    def step_chunk(self, chunk, stream=None):
+        _ck(lib().gmx_pr_step_chunk(self._h, chunk, stream))
+
+    def contrib_next_full(self):
+        p, n = C.c_void_p(), C.c_int64(0)
+        _ck(lib().gmx_pr_contrib_next_full(self._h, C.byref(p), C.byref(n)))
+        return DevArray(p.value, n.value, self._typestr())
 
     def diff(self, stream=None):
         v = C.c_double(0)

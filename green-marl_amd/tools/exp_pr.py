@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--bfs", type=int, default=1)
     ap.add_argument("--tc", type=int, default=0)
     ap.add_argument("--nranks", type=int, default=1, help="time rank 0 of N ranks (no exchange: timing only)")
+    ap.add_argument("--chunks", type=int, default=1, help="row chunks per step (gmx_pr_set_chunks)")
     args = ap.parse_args()
     print(gmx.device_info(), flush=True)
     for scale in [int(s) for s in args.scales.split(",")]:
@@ -34,6 +35,8 @@ def main():
                 for opt in [int(s) for s in args.opts.split(",")]:
                     t0 = time.time()
                     st = gmx.PageRankState(g, elem, 0, args.nranks, opt)
+                    if args.chunks > 1:
+                        st.set_chunks(args.chunks)
                     st.reset(0.85)
                     t1 = time.time()
                     for _ in range(2):

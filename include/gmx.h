@@ -144,6 +144,18 @@ int gmx_pr_free(gmx_pr_t* p);
 int gmx_pr_reset(gmx_pr_t* p, double d);                 /* rank = 1/N, contrib = rank/outdeg, cnt = 0 */
 /* Enqueue one iteration on `stream` (a hipStream_t, NULL = default stream). Asynchronous. */
 int gmx_pr_step(gmx_pr_t* p, void* stream);
+/* Row chunks: with C > 1 a step is enqueued as C pieces (gmx_pr_step_chunk 0..C-1, in that order), each
+ * finishing the new contributions of one sub-range [offset, offset+count) of the rank's exchanged prefix
+ * (gmx_pr_chunk_range; identical on every rank, together they tile [0, gmx_pr_exchange_count)), so that
+ * the exchange of chunk c runs while chunk c+1 is computed.  The sub-ranges are walked from the back: the
+ * first pieces hold most of the rows but few edges, the last one the hubs.  gmx_pr_step() enqueues all
+ * chunks.  Only the sliced variant splits; otherwise the chunk count stays 1.
+ * gmx_pr_contrib_next_full is the replica the running step writes. */
+int gmx_pr_set_chunks(gmx_pr_t* p, int chunks);
+int gmx_pr_num_chunks(gmx_pr_t* p, int* chunks);
+int gmx_pr_chunk_range(gmx_pr_t* p, int chunk, int64_t* offset, int64_t* count);
+int gmx_pr_step_chunk(gmx_pr_t* p, int chunk, void* stream);
+int gmx_pr_contrib_next_full(gmx_pr_t* p, void** dev_ptr, int64_t* count);
 /* Device pointer + element count of the slice of the *current* contribution
  * vector this rank produced in the last step (for the exchange), and of the
  * whole replica. */

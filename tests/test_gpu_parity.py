@@ -234,6 +234,57 @@ def test_pagerank_partitioned_ranks_in_one_process(gmx, nranks, options):
     g.free()
 
 
+@pytest.mark.parametrize("scale,nranks,chunks,elem", [(15, 2, 4, 8), (15, 4, 3, 8), (15, 1, 8, 8), (18, 2, 8, 8), (18, 8, 4, 4),
+                                                       (12, 2, 4, 8)])
+def test_pagerank_row_chunked_steps(gmx, scale, nranks, chunks, elem):
+    """gmx_pr_step_chunk: a sweep enqueued as C row chunks, each chunk's piece exchanged (device copies
+    standing in for the all-gather) before the next chunk is computed -- the order of events of the
+    overlapped N > 1 step.  Ranks, diff and iteration behaviour must equal the unchunked run / the oracle."""
+    import torch
+    og = po.rmat_graph(scale, permute=True)
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    iters = 8
+    want, it, want_diff = po.pagerank(og, 1e-300, 0.85, iters)
+    options = gmx.GMX_PR_RELABEL | gmx.GMX_PR_HOT_LDS | gmx.GMX_PR_SLICED
+    states = [gmx.PageRankState(g, elem, r, nranks, options) for r in range(nranks)]
+    for s in states:
+        assert s.set_chunks(chunks) == chunks
+    ranges = [states[0].chunk_range(c) for c in range(chunks)]
+    need = states[0].exchange_count()
+    assert all([s.chunk_range(c) for c in range(chunks)] == ranges for s in states)
+    # processing order walks the exchanged prefix from the back; together the pieces tile [0, need)
+    assert ranges[-1][0] == 0 and sum(cnt for _, cnt in ranges) == need
+    assert all(ranges[c + 1][0] + ranges[c + 1][1] == ranges[c][0] for c in range(chunks - 1))
+    assert ranges[0][0] + ranges[0][1] == need
+    for s in states:
+        s.reset(0.85)
+    n = torch.as_tensor(states[0].contrib_slice(), device="cuda").numel()
+    fulls = [torch.as_tensor(s.contrib_full(), device="cuda") for s in states]
+    for dst in fulls:
+        for r, src in enumerate(fulls):
+            dst[r * n:r * n + need].copy_(src[r * n:r * n + need])
+    torch.cuda.synchronize()
+    for _ in range(iters):
+        nxt = [torch.as_tensor(s.contrib_next_full(), device="cuda") for s in states]
+        for c, (off, cnt) in enumerate(ranges):
+            for s in states:
+                s.step_chunk(c)
+            for dst in nxt:
+                for r, src in enumerate(nxt):
+                    if dst is not src:
+                        dst[r * n + off:r * n + off + cnt].copy_(src[r * n + off:r * n + off + cnt])
+        torch.cuda.synchronize()
+    out = np.zeros(og.N, dtype=np.float64 if elem == 8 else np.float32)
+    for s in states:
+        s.download(out)
+    assert rel_err(out, want) < (PR_RTOL_F64 if elem == 8 else PR_RTOL_F32)
+    diff = sum(s.diff() for s in states)
+    assert abs(diff - want_diff) <= (1e-9 if elem == 8 else 1e-3) * max(want_diff, 1e-30) + 1e-15
+    for s in states:
+        s.free()
+    g.free()
+
+
 def test_dist_engine_world1_and_kernel_timing(gmx):
     from dist_pagerank import DistPageRank, GmxEngine
     og = po.rmat_graph(14, permute=True)
