@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--edge-factor", type=int, default=16, help="edges per vertex (22 at scale 26 ~ Twitter-2010's 1.47 G edges)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--options", type=int, default=-1, help="gmx_pr_create option bits (default: library default)")
+    ap.add_argument("--chunks", type=int, default=0, help="row chunks per step for N > 1 (0: 2 when the sliced variant runs)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "push", "collective"],
+                    help="N > 1: peer copies over xGMI (hipIpc + copy engines) or RCCL all-gather; auto = push if it sets up")
     ap.add_argument("--cpu-scale", type=int, default=24)
     ap.add_argument("--cpu-iters", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true")
@@ -99,7 +102,12 @@ def main():
     t0 = time.perf_counter()
     graph = gmx.Graph.rmat(N, M, 1997, 0.57, 0.19, 0.19, True)
     engine = GmxEngine(gmx, graph, elem, rank, world, options)
-    pr = DistPageRank(engine, always_exchange=force_coll)
+    chunks = 1
+    if world > 1 or force_coll:
+        # chunked step: the low-degree tail of the rank's range is reduced first and travels while the hubs
+        # (most of the sweep) are reduced
+        chunks = engine.set_chunks(args.chunks if args.chunks > 0 else 2)
+    pr = DistPageRank(engine, always_exchange=force_coll, exchange=args.exchange if world > 1 else "collective")
     pr.reset(0.85)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
@@ -149,7 +157,10 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "pagerank RMAT-%d (V=%d, E=%d), reference RMAT generator seed 1997 permute=1, "
                                    "d=0.85, fixed iterations" % (args.scale, N, M),
-                       "partition": "1-D vertex, %d rank(s), all-gather of contribution slices" % world,
+                       "partition": "1-D vertex, %d rank(s)" % world,
+                       "exchange": "none" if world == 1 and not force_coll else
+                                   ("peer copies over xGMI (hipIpc, copy engines), %d row chunk(s), barrier = all-reduce of diff"
+                                    if pr.exchange == "push" else "RCCL all-gather of contribution slices, %d row chunk(s)") % chunks,
                        "options": options, "setup_s": round(setup_s, 2), "last_diff": last_diff},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

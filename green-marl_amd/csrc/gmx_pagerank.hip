@@ -113,12 +113,27 @@ struct gmx_pr {
     dbuf<char> sl_partial;
     dbuf<unsigned int> sl_queue;
     int64_t sl_nblk_total = 0;
+    // peer push (exchange over xGMI by the copy engines): the other ranks' replicas mapped into this
+    // process, one copy stream per peer
+    int step_next = 1;                       // replica the running step writes
+    std::vector<char*> peer_buf[2];          // [nranks] base of rank r's contrib[b]; own entry unused
+    std::vector<hipStream_t> push_stream;    // [nranks]
+    std::vector<hipEvent_t> push_done;       // [nranks]
+    hipEvent_t push_ready = nullptr;         // "this chunk is computed", recorded on the step's stream
     // dominant-kernel timing (hipEvents on the launch stream)
     bool timing = false;
     std::vector<hipEvent_t> ev;   // pairs
     int ev_used = 0;
     ~gmx_pr() {
         for (hipEvent_t e : ev) (void) hipEventDestroy(e);
+        for (hipStream_t st : push_stream)
+            if (st) {
+                (void) hipStreamSynchronize(st);
+                (void) hipStreamDestroy(st);
+            }
+        for (hipEvent_t e : push_done)
+            if (e) (void) hipEventDestroy(e);
+        if (push_ready) (void) hipEventDestroy(push_ready);
     }
 };
 
@@ -1480,7 +1495,10 @@ extern "C" int gmx_pr_step_chunk(gmx_pr_t* p, int chunk, void* stream) {
     GMX_REQUIRE(p, "pr is NULL");
     GMX_REQUIRE(chunk >= 0 && chunk < p->nchunks, "chunk %d out of range", chunk);
     hipStream_t s = (hipStream_t) stream;
-    if (chunk == 0) pr_ev_begin(p, s);   // one "launch" of the roofline = all kernels of one step
+    if (chunk == 0) {
+        pr_ev_begin(p, s);   // one "launch" of the roofline = all kernels of one step
+        p->step_next = 1 - p->cur;
+    }
     if (p->ns > 0) {
         if (p->rows > 0) {
             if (p->elem == 4) launch_sliced_chunk<float>(p, chunk, s);
@@ -1515,6 +1533,99 @@ extern "C" int gmx_pr_contrib_next_full(gmx_pr_t* p, void** dev_ptr, int64_t* co
     GMX_REQUIRE(p && dev_ptr && count, "NULL argument");
     *dev_ptr = p->contrib[1 - p->cur].p;
     *count = p->Vpad;
+    return GMX_OK;
+}
+
+// ------------------------------------------------------------------ peer push
+// The exchange without a collective kernel: every rank maps the other ranks' replicas (hipIpc handles, passed
+// around by the host side) and, as soon as a chunk of its own range is computed, copies that piece straight
+// into each peer's replica -- one hipMemcpyAsync per peer on its own stream, i.e. the SDMA engines over the
+// point-to-point xGMI links, all 7 at once, while the CUs go on with the next chunk.  Ordering between
+// ranks (nobody reads a replica before every piece has landed, nobody overwrites one still being read) is
+// the caller's per-step barrier: the all-reduce of `diff` the algorithm needs anyway.
+extern "C" int gmx_ipc_export(void* dev_ptr, void* handle) {
+    GMX_REQUIRE(dev_ptr && handle, "NULL argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == GMX_IPC_HANDLE_BYTES, "handle size");
+    GMX_HIP(hipIpcGetMemHandle((hipIpcMemHandle_t*) handle, dev_ptr));
+    return GMX_OK;
+}
+
+extern "C" int gmx_ipc_open(const void* handle, void** dev_ptr) {
+    GMX_REQUIRE(dev_ptr && handle, "NULL argument");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    GMX_HIP(hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return GMX_OK;
+}
+
+extern "C" int gmx_ipc_close(void* dev_ptr) {
+    GMX_REQUIRE(dev_ptr, "NULL argument");
+    GMX_HIP(hipIpcCloseMemHandle(dev_ptr));
+    return GMX_OK;
+}
+
+extern "C" int gmx_pr_contrib_buffers(gmx_pr_t* p, void** buf0, void** buf1, int64_t* bytes) {
+    GMX_REQUIRE(p && buf0 && buf1 && bytes, "NULL argument");
+    *buf0 = p->contrib[0].p;
+    *buf1 = p->contrib[1].p;
+    *bytes = p->Vpad * p->elem;
+    return GMX_OK;
+}
+
+extern "C" int gmx_pr_set_peers(gmx_pr_t* p, void* const* peer_buf0, void* const* peer_buf1) {
+    GMX_REQUIRE(p && peer_buf0 && peer_buf1, "NULL argument");
+    for (int r = 0; r < p->nranks; r++)
+        if (r != p->rank) GMX_REQUIRE(peer_buf0[r] && peer_buf1[r], "peer %d: NULL replica pointer", r);
+    if (p->push_stream.empty()) {
+        p->push_stream.assign((size_t) p->nranks, nullptr);
+        p->push_done.assign((size_t) p->nranks, nullptr);
+        for (int r = 0; r < p->nranks; r++) {
+            if (r == p->rank) continue;
+            GMX_HIP(hipStreamCreateWithFlags(&p->push_stream[r], hipStreamNonBlocking));
+            GMX_HIP(hipEventCreateWithFlags(&p->push_done[r], hipEventDisableTiming));
+        }
+        GMX_HIP(hipEventCreateWithFlags(&p->push_ready, hipEventDisableTiming));
+    }
+    p->peer_buf[0].assign((char* const*) peer_buf0, (char* const*) peer_buf0 + p->nranks);
+    p->peer_buf[1].assign((char* const*) peer_buf1, (char* const*) peer_buf1 + p->nranks);
+    return GMX_OK;
+}
+
+// entries [offset, offset+count) of this rank's range, from replica b to the same place in every peer's replica b
+static int pr_push_range(gmx_pr* p, int b, int64_t offset, int64_t count, hipStream_t s) {
+    if (p->nranks == 1) return GMX_OK;
+    GMX_REQUIRE(!p->peer_buf[0].empty(), "gmx_pr_set_peers has not been called");
+    GMX_REQUIRE(offset >= 0 && count >= 0 && offset + count <= p->slice, "push range outside the rank's range");
+    if (count == 0) return GMX_OK;
+    GMX_HIP(hipEventRecord(p->push_ready, s));
+    const size_t at = (size_t) (p->row_lo + offset) * p->elem, bytes = (size_t) count * p->elem;
+    for (int i = 1; i < p->nranks; i++) {
+        const int r = (p->rank + i) % p->nranks;   // every rank starts with a different peer
+        GMX_HIP(hipStreamWaitEvent(p->push_stream[r], p->push_ready, 0));
+        GMX_HIP(hipMemcpyAsync(p->peer_buf[b][r] + at, p->contrib[b].p + at, bytes, hipMemcpyDeviceToDevice, p->push_stream[r]));
+    }
+    return GMX_OK;
+}
+
+extern "C" int gmx_pr_push_chunk(gmx_pr_t* p, int chunk, void* stream) {
+    GMX_REQUIRE(p, "pr is NULL");
+    int64_t off = 0, cnt = 0;
+    GMX_CHECK(gmx_pr_chunk_range(p, chunk, &off, &cnt));
+    return pr_push_range(p, p->step_next, off, cnt, (hipStream_t) stream);
+}
+
+extern "C" int gmx_pr_push_current(gmx_pr_t* p, void* stream) {
+    GMX_REQUIRE(p, "pr is NULL");
+    return pr_push_range(p, p->cur, 0, p->exchange_count, (hipStream_t) stream);
+}
+
+extern "C" int gmx_pr_push_join(gmx_pr_t* p, void* stream) {
+    GMX_REQUIRE(p, "pr is NULL");
+    for (int r = 0; r < (int) p->push_stream.size(); r++) {
+        if (!p->push_stream[r]) continue;
+        GMX_HIP(hipEventRecord(p->push_done[r], p->push_stream[r]));
+        GMX_HIP(hipStreamWaitEvent((hipStream_t) stream, p->push_done[r], 0));
+    }
     return GMX_OK;
 }
 

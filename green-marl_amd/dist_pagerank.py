@@ -13,6 +13,10 @@ with the sweep split over ranks:
   * with C > 1 row chunks (engine.set_chunks) the sweep is enqueued chunk by chunk and the all-gather of
     chunk c's freshly written piece runs (async, on the process group's own stream) while chunk c+1 is
     computed -- the exchange hides behind the sweep instead of following it;
+  * exchange="push" replaces the all-gather by direct copies: the ranks map each other's replicas (hipIpc)
+    and every rank copies each finished chunk into all peers' replicas with the copy engines over the
+    point-to-point xGMI links (gmx_pr_push_*), which needs no CUs and therefore really runs under the
+    persistent sweep kernel; the per-step barrier that orders the ranks is the all-reduce of `diff`;
   * `diff` is a 1-element fp64 all-reduce(SUM) -- the ATOMIC_ADD<double>(&diff, diff_prv) of the
     emitted code with ranks in place of threads.
 
@@ -62,6 +66,22 @@ class GmxEngine:
     def contrib_next_full(self):
         return self._wrap(self.state.contrib_next_full())
 
+    # peer push
+    def ipc_handles(self):
+        return self.state.ipc_handles()
+
+    def set_peers(self, handles):
+        self.state.set_peers(handles)
+
+    def push_chunk(self, chunk):
+        self.state.push_chunk(chunk, None)
+
+    def push_current(self):
+        self.state.push_current(None)
+
+    def push_join(self):
+        self.state.push_join(None)
+
     def contrib_slice(self):
         return self._wrap(self.state.contrib_slice())
 
@@ -79,7 +99,12 @@ class GmxEngine:
 
 
 class DistPageRank:
-    def __init__(self, engine, group=None, always_exchange=False):
+    """exchange: "collective" (all-gather), "push" (peer copies, engine must offer ipc_handles/set_peers/push_*),
+    or "auto" (push if every rank could map its peers, else collective).
+    barrier: how ranks are ordered after a pushed step -- "collective" (all-reduce of diff on the device, the
+    production path) or "host" (stream sync + host barrier; for ranks sharing one GPU, where RCCL cannot run)."""
+
+    def __init__(self, engine, group=None, always_exchange=False, exchange="collective", barrier="collective"):
         self.engine = engine
         self.group = group
         self.initialized = dist.is_available() and dist.is_initialized()
@@ -87,9 +112,64 @@ class DistPageRank:
         # always_exchange: issue the collectives even with one rank (exercises the RCCL path on a 1-GPU box)
         self.always_exchange = always_exchange and self.initialized
         self.cnt = 0
+        self.barrier = barrier
+        self._diff = None
+        self.exchange = "collective"
+        if exchange in ("push", "auto") and self.world > 1:
+            self.exchange = "push" if self._setup_push(exchange == "push") else "collective"
+
+    def _setup_push(self, required):
+        """Pass the replica handles around and map the peers'; every rank must succeed or none uses it."""
+        ok, err = 1, None
+        try:
+            mine = self.engine.ipc_handles()
+        except Exception as e:   # noqa: BLE001 -- any failure means "no push here", reported below
+            mine, ok, err = None, 0, e
+        handles = [None] * self.world
+        dist.all_gather_object(handles, mine, group=self.group)
+        if ok and all(h is not None for h in handles):
+            try:
+                self.engine.set_peers(handles)
+            except Exception as e:   # noqa: BLE001
+                ok, err = 0, e
+        else:
+            ok = 0
+        flags = [None] * self.world
+        dist.all_gather_object(flags, ok, group=self.group)
+        if all(flags):
+            return True
+        if required:
+            raise RuntimeError("peer push unavailable on rank(s) %s: %s" % ([r for r, f in enumerate(flags) if not f], err))
+        return False
+
+    def _rank_barrier(self):
+        """After a pushed step: nobody goes on before every rank's copies have completed.  Carries diff."""
+        t = self.engine.diff_tensor().clone()
+        if self.barrier == "host":
+            import torch
+            if t.is_cuda:
+                torch.cuda.synchronize()
+            t = t.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        self._diff = t
+
+    def _step_pushed(self, chunks):
+        eng = self.engine
+        for c in range(chunks):
+            eng.step_chunk(c)
+            eng.push_chunk(c)      # copies start when the chunk is done, the stream goes on with the next one
+        eng.push_join()
+        self._rank_barrier()
 
     def _exchange(self):
         if self.world == 1 and not self.always_exchange:
+            return
+        if self.exchange == "push":
+            self.engine.push_current()
+            self.engine.push_join()
+            self._rank_barrier()
             return
         full = self.engine.contrib_full()
         mine = self.engine.contrib_slice()
@@ -134,7 +214,10 @@ class DistPageRank:
     def step(self):
         """One PageRank iteration of the whole job (local sweep + exchange); asynchronous on GPU."""
         chunks = self.engine.num_chunks() if hasattr(self.engine, "num_chunks") else 1
-        if chunks > 1 and (self.world > 1 or self.always_exchange):
+        self._diff = None
+        if self.exchange == "push":
+            self._step_pushed(chunks)
+        elif chunks > 1 and (self.world > 1 or self.always_exchange):
             self._step_chunked(chunks)
         else:
             self.engine.step()
@@ -142,6 +225,8 @@ class DistPageRank:
         self.cnt += 1
 
     def diff(self):
+        if self._diff is not None:      # the pushed step's barrier already summed it
+            return float(self._diff.item())
         t = self.engine.diff_tensor()
         if self.world > 1 or self.always_exchange:
             t = t.clone()

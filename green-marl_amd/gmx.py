@@ -47,10 +47,13 @@ EXPORTS = [
     "gmx_pr_create", "gmx_pr_free", "gmx_pr_reset", "gmx_pr_step", "gmx_pr_contrib_slice",
     "gmx_pr_contrib_full", "gmx_pr_exchange_count", "gmx_pr_diff_ptr", "gmx_pr_diff", "gmx_pr_download", "gmx_pr_work",
     "gmx_pr_set_chunks", "gmx_pr_num_chunks", "gmx_pr_chunk_range", "gmx_pr_step_chunk", "gmx_pr_contrib_next_full",
+    "gmx_ipc_export", "gmx_ipc_open", "gmx_ipc_close", "gmx_pr_contrib_buffers", "gmx_pr_set_peers",
+    "gmx_pr_push_chunk", "gmx_pr_push_current", "gmx_pr_push_join",
     "gmx_pr_timing", "gmx_pr_kernel_time", "gmx_pr_kernel_name", "gmx_pr_default_options",
 ]
 
 _LIB = None
+IPC_HANDLE_BYTES = 64   # GMX_IPC_HANDLE_BYTES
 
 
 def lib():
@@ -94,6 +97,14 @@ def lib():
         L.gmx_pr_contrib_slice.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
         L.gmx_pr_contrib_full.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
         L.gmx_pr_diff_ptr.argtypes = [vp, C.POINTER(vp)]
+        L.gmx_ipc_export.argtypes = [vp, vp]
+        L.gmx_ipc_open.argtypes = [vp, C.POINTER(vp)]
+        L.gmx_ipc_close.argtypes = [vp]
+        L.gmx_pr_contrib_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
+        L.gmx_pr_set_peers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+        L.gmx_pr_push_chunk.argtypes = [vp, C.c_int, vp]
+        L.gmx_pr_push_current.argtypes = [vp, vp]
+        L.gmx_pr_push_join.argtypes = [vp, vp]
         L.gmx_pr_set_chunks.argtypes = [vp, C.c_int]
         L.gmx_pr_num_chunks.argtypes = [vp, C.POINTER(C.c_int)]
         L.gmx_pr_chunk_range.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(i64)]
@@ -279,6 +290,41 @@ class PageRankState:
     def step(self, stream=None):
         _ck(lib().gmx_pr_step(self._h, stream))
 
+    # ---- peer push (gmx.h: exchange by direct copies into the peers' replicas) ----
+    def ipc_handles(self):
+        """hipIpc handles (bytes) of the two contribution replicas, to be opened by the other ranks."""
+        b0, b1, n = C.c_void_p(), C.c_void_p(), C.c_int64(0)
+        _ck(lib().gmx_pr_contrib_buffers(self._h, C.byref(b0), C.byref(b1), C.byref(n)))
+        out = []
+        for b in (b0, b1):
+            h = C.create_string_buffer(IPC_HANDLE_BYTES)
+            _ck(lib().gmx_ipc_export(b, h))
+            out.append(h.raw)
+        return out
+
+    def set_peers(self, handles):
+        """handles[r] = rank r's ipc_handles() (own entry ignored): map them and register the pointers."""
+        ptrs = [(C.c_void_p * self.nranks)(), (C.c_void_p * self.nranks)()]
+        self._peer_maps = []
+        for r, hs in enumerate(handles):
+            if r == self.rank:
+                continue
+            for b in (0, 1):
+                q = C.c_void_p()
+                _ck(lib().gmx_ipc_open(C.create_string_buffer(hs[b], IPC_HANDLE_BYTES), C.byref(q)))
+                ptrs[b][r] = q.value
+                self._peer_maps.append(q.value)
+        _ck(lib().gmx_pr_set_peers(self._h, ptrs[0], ptrs[1]))
+
+    def push_chunk(self, chunk, stream=None):
+        _ck(lib().gmx_pr_push_chunk(self._h, chunk, stream))
+
+    def push_current(self, stream=None):
+        _ck(lib().gmx_pr_push_current(self._h, stream))
+
+    def push_join(self, stream=None):
+        _ck(lib().gmx_pr_push_join(self._h, stream))
+
     def set_chunks(self, chunks):
         _ck(lib().gmx_pr_set_chunks(self._h, int(chunks)))
         return self.num_chunks()
@@ -356,8 +402,11 @@ class PageRankState:
 
     def free(self):
         if self._h:
-            lib().gmx_pr_free(self._h)
+            lib().gmx_pr_free(self._h)     # drains the copy streams first
             self._h = None
+            for q in getattr(self, "_peer_maps", []):
+                lib().gmx_ipc_close(q)
+            self._peer_maps = []
 
     def __del__(self):
         try:

@@ -156,6 +156,24 @@ int gmx_pr_num_chunks(gmx_pr_t* p, int* chunks);
 int gmx_pr_chunk_range(gmx_pr_t* p, int chunk, int64_t* offset, int64_t* count);
 int gmx_pr_step_chunk(gmx_pr_t* p, int chunk, void* stream);
 int gmx_pr_contrib_next_full(gmx_pr_t* p, void** dev_ptr, int64_t* count);
+/* Peer push: the exchange of the N > 1 step without a collective kernel.  The host side passes the ranks'
+ * replica handles around (gmx_pr_contrib_buffers -> gmx_ipc_export -> its own transport -> gmx_ipc_open) and
+ * hands the mapped pointers to gmx_pr_set_peers (arrays of nranks entries, own entry ignored).  After
+ * gmx_pr_step_chunk(c, stream), gmx_pr_push_chunk(c, stream) copies the chunk's piece into every peer's
+ * replica on per-peer copy streams (SDMA over xGMI), ordered after the chunk's kernels;
+ * gmx_pr_push_current pushes the whole exchanged prefix of the current replica (after a reset);
+ * gmx_pr_push_join makes `stream` wait for all copies issued so far.  The caller then runs its per-step
+ * barrier (e.g. the all-reduce of diff): a rank may start the next step only after every rank's copies
+ * have completed. */
+#define GMX_IPC_HANDLE_BYTES 64
+int gmx_ipc_export(void* dev_ptr, void* handle /* GMX_IPC_HANDLE_BYTES */);
+int gmx_ipc_open(const void* handle, void** dev_ptr);
+int gmx_ipc_close(void* dev_ptr);
+int gmx_pr_contrib_buffers(gmx_pr_t* p, void** buf0, void** buf1, int64_t* bytes);
+int gmx_pr_set_peers(gmx_pr_t* p, void* const* peer_buf0, void* const* peer_buf1);
+int gmx_pr_push_chunk(gmx_pr_t* p, int chunk, void* stream);
+int gmx_pr_push_current(gmx_pr_t* p, void* stream);
+int gmx_pr_push_join(gmx_pr_t* p, void* stream);
 /* Device pointer + element count of the slice of the *current* contribution
  * vector this rank produced in the last step (for the exchange), and of the
  * whole replica. */

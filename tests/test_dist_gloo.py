@@ -95,6 +95,48 @@ class NumpyEngine:
         return self._diff
 
 
+class SharedFileEngine(NumpyEngine):
+    """NumpyEngine whose replicas live in files every rank can map -- the CPU stand-in for hipIpc-mapped HBM.
+    Implements the peer-push interface of dist_pagerank.GmxEngine (ipc_handles / set_peers / push_*)."""
+
+    def __init__(self, g, rank, world, tmp_dir):
+        super().__init__(g, rank, world)
+        self.paths = [os.path.join(tmp_dir, "replica_r%d_b%d.bin" % (rank, b)) for b in (0, 1)]
+        maps = [np.memmap(p, dtype=np.float64, mode="w+", shape=(self.slice * world,)) for p in self.paths]
+        self.contrib = [torch.from_numpy(m) for m in maps]
+        self.peers = None
+
+    def ipc_handles(self):
+        return list(self.paths)
+
+    def set_peers(self, handles):
+        self.peers = [None if r == self.rank else
+                      [np.memmap(p, dtype=np.float64, mode="r+", shape=(self.slice * self.world,)) for p in hs]
+                      for r, hs in enumerate(handles)]
+
+    def _push(self, b, off, cnt):
+        lo = self.rank * self.slice + off
+        src = self.contrib[b].numpy()[lo:lo + cnt]
+        for r, maps in enumerate(self.peers):
+            if maps is not None:
+                maps[b][lo:lo + cnt] = src
+                maps[b].flush()
+
+    def step_chunk(self, c):
+        if c == 0:
+            self.step_next = 1 - self.cur
+        super().step_chunk(c)
+
+    def push_chunk(self, c):
+        self._push(self.step_next, *self.chunk_range(c))
+
+    def push_current(self):
+        self._push(self.cur, 0, self.slice)
+
+    def push_join(self):
+        pass
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -103,7 +145,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, scale, out_dir, chunks=1):
+def _worker(rank, world, port, scale, out_dir, chunks=1, push=False):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (os.path.join(here, "..", "green-marl_amd"), os.path.join(here, "..", "oracle")):
@@ -113,9 +155,10 @@ def _worker(rank, world, port, scale, out_dir, chunks=1):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = po.rmat_graph(scale, permute=True)
-    eng = NumpyEngine(g, rank, world)
+    eng = SharedFileEngine(g, rank, world, out_dir) if push else NumpyEngine(g, rank, world)
     eng.set_chunks(chunks)
-    pr = DistPageRank(eng)
+    pr = DistPageRank(eng, exchange="push", barrier="host") if push else DistPageRank(eng)
+    assert pr.exchange == ("push" if push else "collective")
     cnt, diff = pr.run(0.001, 0.85, 100)
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), eng.rank_v)
     np.save(os.path.join(out_dir, "meta%d.npy" % rank), np.array([cnt, diff, eng.lo, eng.hi]))
@@ -123,12 +166,15 @@ def _worker(rank, world, port, scale, out_dir, chunks=1):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 1), (2, 4), (3, 3)])
-def test_dist_pagerank_gloo(tmp_path, world, chunks):
+@pytest.mark.parametrize("world,chunks,push", [(2, 1, False), (3, 1, False), (2, 4, False), (3, 3, False),
+                                                (2, 1, True), (3, 2, True)])
+def test_dist_pagerank_gloo(tmp_path, world, chunks, push):
     """chunks > 1: the sweep is enqueued in row chunks and each chunk's piece is all-gathered (async) while
-    the next chunk is computed -- the overlap path the GPU ranks take for N > 1."""
+    the next chunk is computed -- the overlap path the GPU ranks take for N > 1.
+    push: the exchange by direct copies into the peers' replicas (files here, hipIpc-mapped HBM on the GPUs),
+    ordered by the per-step all-reduce of diff."""
     scale = 11
-    mp.spawn(_worker, args=(world, _free_port(), scale, str(tmp_path), chunks), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), scale, str(tmp_path), chunks, push), nprocs=world, join=True)
     g = po.rmat_graph(scale, permute=True)
     want, it, want_diff = po.pagerank(g, 0.001, 0.85, 100, nthreads=1)
     got = np.zeros(g.N)

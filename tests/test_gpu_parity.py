@@ -4,6 +4,8 @@ against the CPU oracle on the same inputs and against the committed golden fixtu
 Bars: bit-exact for integer work (CSR construction, BFS levels, triangle counts);
 PageRank within 1e-6 relative of the fp64 CPU result with the same iteration count
 (BASELINE.json north_star), fp64 mode within 1e-12."""
+import os
+
 import numpy as np
 import pytest
 
@@ -283,6 +285,35 @@ def test_pagerank_row_chunked_steps(gmx, scale, nranks, chunks, elem):
     for s in states:
         s.free()
     g.free()
+
+
+@pytest.mark.parametrize("world,chunks,elem", [(3, 2, 8), (2, 1, 4)])
+def test_peer_push_exchange_between_processes(gmx, world, chunks, elem):
+    """The N > 1 exchange by direct copies into the peers' hipIpc-mapped replicas, with real processes (one
+    per rank, sharing this box's single GPU; see tests/mp_push_worker.py)."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mp_push_worker.py")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, worker, "15", str(chunks), str(elem), "8"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=300)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "-> OK" in outs[0], outs[0]
 
 
 def test_dist_engine_world1_and_kernel_timing(gmx):
