@@ -48,9 +48,10 @@ struct pr_slice_desc {
     const int32_t* ridx;
     double* part_first;
     double* part_last;
-    void* partial;   // [rows of the rank] row sums restricted to this slice (element type S); rows the
-                     // slice has no edge for keep the 0 they were initialised with (the graph is static)
-    const int32_t* rowid;   // compact row -> local row: only rows with at least one edge in the slice are stored
+    void* partial;   // [active rows of the rank] row sums restricted to this slice (element type S), indexed by
+                     // the row's position in active[]; rows the slice has no edge for keep the 0 they were
+                     // initialised with (the graph is static)
+    const int32_t* rowid;   // compact row -> position in active[]: only rows with an edge in the slice are stored
     int64_t crows;          // number of compact rows
     // per launch (row chunk): blocks [k_lo, k_hi) are reduced, openers [f_lo, f_hi) are fixed up
     int64_t k_lo, k_hi, f_lo, f_hi;
@@ -103,6 +104,9 @@ struct gmx_pr {
     dbuf<int32_t> sl_rb, sl_ridx, sl_rowid, sl_active;   // sl_active: local rows with in-edges
     dbuf<uint8_t> sl_is_active;
     int64_t sl_nactive = 0;
+    dbuf<int32_t> sl_outdeg_c;   // [nactive] out-degree of active row i (dense copy for the combine pass)
+    dbuf<char> sl_rk_c;          // [nactive] x elem: rank of active row i; rk[] holds the rows without in-edges
+
     // row chunks of a step (1 = whole step at once); tables from pr_chunk_table_kernel
     int nchunks = 1;
     int64_t ch_row[PR_MAX_CHUNKS + 1];                       // boundary rows
@@ -897,22 +901,58 @@ __global__ void pr_sliced_fixup_kernel(pr_sliced_args a, int64_t rows) {
 // Sum the slices in fixed order and apply the PageRank update.  Only rows that have in-edges are
 // visited (active[]): a row without in-edges gets (1-d)/N in the first sweep and never changes again
 // (SURVEY.md appendix A), so pr_inactive_first_kernel settles those once, right after a reset.
+// Everything the pass streams is indexed by the position i in active[] (partial sums, out-degree, rank), so
+// it reads whole lines of useful data although only ~40 % of the rows are active; the one row-indexed access
+// is the store of the new contribution.
 template <typename S>
 __global__ void __launch_bounds__(256)
-pr_combine_kernel(pr_sliced_args a, const int32_t* __restrict__ active, int64_t nactive,
-                  const int32_t* __restrict__ outdeg, S* __restrict__ rk,
+pr_combine_kernel(pr_sliced_args a, const int32_t* __restrict__ active, int64_t i_lo, int64_t i_hi,
+                  const int32_t* __restrict__ outdeg_c, S* __restrict__ rk_c,
                   S* __restrict__ contrib_next_owned, double base, double d, double* __restrict__ diff_part) {
     __shared__ double s_red[256 / 64];
     double diff_acc = 0.0;
+    int64_t i = i_lo + (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < i_hi; i += stride) {
+        const int64_t r = __builtin_nontemporal_load(active + i);
+        double sum = 0.0;
+        for (int sl = 0; sl < a.ns; sl++) sum += (double) __builtin_nontemporal_load((const S*) a.s[sl].partial + i);
+        const int32_t od = __builtin_nontemporal_load(outdeg_c + i);
+        const double val = base + d * sum;
+        const double old = (double) __builtin_nontemporal_load(rk_c + i);
+        const S vs = (S) val;
+        diff_acc += fabs((double) vs - old);
+        __builtin_nontemporal_store(vs, rk_c + i);
+        __builtin_nontemporal_store(od > 0 ? (S) ((double) vs / (double) od) : (S) 0, contrib_next_owned + r);
+    }
+    pr_block_diff<256>(diff_acc, s_red, diff_part + blockIdx.x);
+}
+
+// Plan: position of every active row in active[]; the slices' compact rows are renamed to it.
+__global__ void pr_active_index_kernel(const int32_t* __restrict__ active, int64_t nactive, int32_t* __restrict__ index_of_row) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < nactive; i += stride) index_of_row[active[i]] = (int32_t) i;
+}
+__global__ void pr_remap_kernel(int32_t* __restrict__ ids, int64_t n, const int32_t* __restrict__ map) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) ids[i] = map[ids[i]];
+}
+__global__ void pr_gather_i32_kernel(const int32_t* __restrict__ active, int64_t nactive, const int32_t* __restrict__ src, int32_t* __restrict__ dst) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < nactive; i += stride) dst[i] = src[active[i]];
+}
+// rank of the active rows: dense <-> row order (reset / download)
+template <typename S>
+__global__ void pr_rk_dense_kernel(const int32_t* __restrict__ active, int64_t nactive, S* __restrict__ rk, S* __restrict__ rk_c, int to_rows) {
     int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
     for (; i < nactive; i += stride) {
-        const int64_t r = __builtin_nontemporal_load(active + i);
-        double sum = 0.0;
-        for (int sl = 0; sl < a.ns; sl++) sum += (double) __builtin_nontemporal_load((const S*) a.s[sl].partial + r);
-        pr_finalize<S>(r, sum, base, d, rk, outdeg, contrib_next_owned, diff_acc);
+        if (to_rows) rk[active[i]] = rk_c[i];
+        else rk_c[i] = rk[active[i]];
     }
-    pr_block_diff<256>(diff_acc, s_red, diff_part + blockIdx.x);
 }
 
 // First sweep after a reset: rows with no in-edges get their (from now on constant) rank and contribution.
@@ -964,10 +1004,15 @@ __global__ void pr_chunk_table_kernel(pr_sliced_args a, const int32_t* __restric
         return;
     }
     const pr_slice_desc& sd = a.s[sl];
+    int64_t alo = 0, ahi = nactive;
+    while (alo < ahi) {   // position in active[] of the first row >= B
+        int64_t mid = (alo + ahi) >> 1;
+        if (active[mid] < B) alo = mid + 1; else ahi = mid;
+    }
     int64_t lo = 0, hi = sd.crows;
-    while (lo < hi) {   // first compact row whose local row >= B
+    while (lo < hi) {   // first compact row at or after it (compact rows are named by their position in active[])
         int64_t mid = (lo + hi) >> 1;
-        if (sd.rowid[mid] < B) lo = mid + 1; else hi = mid;
+        if (sd.rowid[mid] < alo) lo = mid + 1; else hi = mid;
     }
     // path position of a row's first item = edges before it + row ends before it
     out[t] = lo < sd.crows ? ((int64_t) sd.rb[lo] + lo) / items : sd.nblk;
@@ -1210,6 +1255,21 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 hipLaunchKernelGGL(pr_slice_pairs_kernel, dim3(grid_for(El)), dim3(256), 0, s, (const uint64_t*) vals.p,
                                    (const uint8_t*) sk2.p, (const int32_t*) flag.p, (const int32_t*) pos.p, (const int64_t*) off.p,
                                    El, p->row_lo, p->sl_rowid.p, p->sl_rb.p);
+                {   // name the compact rows by their position in active[] and make the dense per-active-row copies
+                    const size_t na = (size_t) (p->sl_nactive ? p->sl_nactive : 1);
+                    dbuf<int32_t> index_of_row;
+                    if ((st = index_of_row.alloc((size_t) (rows ? rows : 1))) || (st = p->sl_outdeg_c.alloc(na)) ||
+                        (st = p->sl_rk_c.alloc(na * elem_bytes))) break;
+                    if (p->sl_nactive > 0) {
+                        hipLaunchKernelGGL(pr_active_index_kernel, dim3(grid_for(p->sl_nactive)), dim3(256), 0, s,
+                                           (const int32_t*) p->sl_active.p, p->sl_nactive, index_of_row.p);
+                        if (npairs > 0)
+                            hipLaunchKernelGGL(pr_remap_kernel, dim3(grid_for(npairs)), dim3(256), 0, s, p->sl_rowid.p, npairs, (const int32_t*) index_of_row.p);
+                        hipLaunchKernelGGL(pr_gather_i32_kernel, dim3(grid_for(p->sl_nactive)), dim3(256), 0, s,
+                                           (const int32_t*) p->sl_active.p, p->sl_nactive, (const int32_t*) p->outdeg.p, p->sl_outdeg_c.p);
+                    }
+                    if (hipStreamSynchronize(s) != hipSuccess) { gmx_set_error("pr plan: active-row renaming failed"); st = GMX_ERR_HIP; break; }
+                }
                 int64_t nblk_s[PR_MAX_SLICES], blk_off[PR_MAX_SLICES + 1];
                 blk_off[0] = 0;
                 for (int q = 0; q < ns; q++) {
@@ -1223,7 +1283,8 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 if (st) break;
                 p->sl_nblk_total = blk_off[ns];
                 size_t npart = (size_t) (p->sl_nblk_total ? p->sl_nblk_total : 1);
-                const size_t partial_bytes = (size_t) ns * (size_t) (rows ? rows : 1) * elem_bytes;
+                const size_t nact_alloc = (size_t) (p->sl_nactive ? p->sl_nactive : 1);
+                const size_t partial_bytes = (size_t) ns * nact_alloc * elem_bytes;
                 if ((st = p->sl_blk.alloc(npart)) || (st = p->sl_part_first.alloc(npart)) || (st = p->sl_part_last.alloc(npart)) ||
                     (st = p->sl_partial.alloc(partial_bytes)) || (st = p->sl_queue.alloc(PR_MAX_SLICES * PR_QUEUE_STRIDE))) break;
                 if (hipMemset(p->sl_partial.p, 0, partial_bytes) != hipSuccess) { gmx_set_error("pr plan: memset failed"); st = GMX_ERR_HIP; break; }
@@ -1238,7 +1299,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                     sd.ridx = p->sl_ridx.p + hoff[q];
                     sd.part_first = p->sl_part_first.p + blk_off[q];
                     sd.part_last = p->sl_part_last.p + blk_off[q];
-                    sd.partial = p->sl_partial.p + (size_t) q * (size_t) rows * elem_bytes;
+                    sd.partial = p->sl_partial.p + (size_t) q * nact_alloc * elem_bytes;
                     sd.rowid = p->sl_rowid.p + pair_off[q];
                     sd.crows = pair_off[q + 1] - pair_off[q];
                     hipLaunchKernelGGL(pr_blocks_kernel, dim3(grid_for(nblk_s[q] + 1, 256, 1 << 30)), dim3(256), 0, s,
@@ -1299,6 +1360,14 @@ extern "C" int gmx_pr_reset(gmx_pr_t* p, double d) {
         else
             hipLaunchKernelGGL(pr_reset_kernel<double>, dim3(grid_for(p->rows)), dim3(256), 0, 0, p->rows, (double) p->V,
                                p->outdeg.p, (double*) p->rk.p, (double*) p->contrib[0].p + p->row_lo);
+        if (p->ns > 0 && p->sl_nactive > 0) {
+            if (p->elem == 4)
+                hipLaunchKernelGGL(pr_rk_dense_kernel<float>, dim3(grid_for(p->sl_nactive)), dim3(256), 0, 0, (const int32_t*) p->sl_active.p,
+                                   p->sl_nactive, (float*) p->rk.p, (float*) p->sl_rk_c.p, 0);
+            else
+                hipLaunchKernelGGL(pr_rk_dense_kernel<double>, dim3(grid_for(p->sl_nactive)), dim3(256), 0, 0, (const int32_t*) p->sl_active.p,
+                                   p->sl_nactive, (double*) p->rk.p, (double*) p->sl_rk_c.p, 0);
+        }
     }
     GMX_HIP(hipGetLastError());
     GMX_HIP(hipDeviceSynchronize());
@@ -1443,8 +1512,8 @@ static void launch_sliced_chunk(gmx_pr* p, int c, hipStream_t s) {
     if (maxfix > 0)
         hipLaunchKernelGGL(pr_sliced_fixup_kernel<S>, dim3((unsigned) ((maxfix + 255) / 256), p->ns), dim3(256), 0, s, a, p->rows);
     double* dpart = p->diff_part.p + (int64_t) c * 2 * PR_COMBINE_GRID;
-    hipLaunchKernelGGL(pr_combine_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, a, (const int32_t*) p->sl_active.p + p->ch_act[j],
-                       p->ch_act[j + 1] - p->ch_act[j], p->outdeg.p, (S*) p->rk.p, next_owned, base, p->d, dpart);
+    hipLaunchKernelGGL(pr_combine_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, a, (const int32_t*) p->sl_active.p,
+                       p->ch_act[j], p->ch_act[j + 1], (const int32_t*) p->sl_outdeg_c.p, (S*) p->sl_rk_c.p, next_owned, base, p->d, dpart);
     if (p->cnt == 0) {   // first sweep after a reset: settle the rows without in-edges once
         hipLaunchKernelGGL(pr_inactive_first_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, (const uint8_t*) p->sl_is_active.p,
                            p->ch_row[j], p->ch_row[j + 1], p->outdeg.p, (S*) p->rk.p, next_owned, base, p->d,
@@ -1670,6 +1739,14 @@ extern "C" int gmx_pr_download(gmx_pr_t* p, void* rank_host) {
     dbuf<char> tmp;
     GMX_CHECK(tmp.alloc((size_t) p->V * p->elem));
     if (p->nranks > 1) GMX_HIP(hipMemcpy(tmp.p, rank_host, (size_t) p->V * p->elem, hipMemcpyHostToDevice));
+    if (p->ns > 0 && p->sl_nactive > 0) {   // the sliced step keeps the ranks of the rows with in-edges densely
+        if (p->elem == 4)
+            hipLaunchKernelGGL(pr_rk_dense_kernel<float>, dim3(grid_for(p->sl_nactive)), dim3(256), 0, 0, (const int32_t*) p->sl_active.p,
+                               p->sl_nactive, (float*) p->rk.p, (float*) p->sl_rk_c.p, 1);
+        else
+            hipLaunchKernelGGL(pr_rk_dense_kernel<double>, dim3(grid_for(p->sl_nactive)), dim3(256), 0, 0, (const int32_t*) p->sl_active.p,
+                               p->sl_nactive, (double*) p->rk.p, (double*) p->sl_rk_c.p, 1);
+    }
     if (p->elem == 4)
         hipLaunchKernelGGL(pr_unpermute_kernel<float>, dim3(grid_for(p->rows)), dim3(256), 0, 0, p->rows, p->inv.p, (const float*) p->rk.p, (float*) tmp.p);
     else
