@@ -729,24 +729,28 @@ pr_wave_sliced_kernel(pr_sliced_args a, int64_t ncontrib, const S* __restrict__ 
     // the static deal is keyed by blockIdx alone (unique by construction); workgroups go round-robin over
     // the 8 XCDs, so this is the home slice
     const int st_slice = (int) ((blockIdx.x & 7) % a.ns);
-    const int st_idx = (int) (((blockIdx.x >> 3) * (8 / a.ns) + (blockIdx.x & 7) / a.ns) * WAVES + wv);
-    int st_round = 0;
+    const int st_qc = a.s[st_slice].qchunk;
+    // this wave's static claims: st_next, st_next + st_stride, ... (st_left of them)
+    long long st_next = a.s[st_slice].k_lo +
+                        (long long) ((((blockIdx.x >> 3) * (8 / a.ns) + (blockIdx.x & 7) / a.ns) * WAVES + wv)) * st_qc;
+    const long long st_stride = (long long) a.s[st_slice].st_waves * st_qc;
+    int st_left = a.s[st_slice].st_rounds;
     auto claim = [&](long long& k_out, int& sl_out) {
         long long k = -1;
         if (k_next < k_end) k = k_next++;
-        else if (st_round < a.s[st_slice].st_rounds) {
-            const pr_slice_desc& sd = a.s[st_slice];
-            k = sd.k_lo + ((long long) st_round * sd.st_waves + st_idx) * sd.qchunk;
-            st_round++;
+        else if (st_left > 0) {
+            k = st_next;
+            st_next += st_stride;
+            st_left--;
             k_next = k + 1;
-            k_end = k + sd.qchunk;   // static claims are whole and inside the window
+            k_end = k + st_qc;   // static claims are whole and inside the window
             cur = st_slice;
         } else {
             for (int t = first_try; t < a.ns; t++) {
                 cur = (home + t) % a.ns;
                 first_try = t + 1;
                 // a queue some wave of this workgroup has seen empty costs an LDS read, not another atomic
-                if (*(volatile int*) &s_drained[cur]) continue;
+                if (__builtin_amdgcn_readfirstlane(*(volatile int*) &s_drained[cur])) continue;   // (scalar: keeps the loop uniform)
                 const long long nb = a.s[cur].k_hi;
                 const int qc = a.s[cur].qchunk;
                 unsigned int kk0 = 0;
@@ -1080,7 +1084,9 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
     p->V = g->V;
     const bool relabel = (options & GMX_PR_RELABEL) != 0;
     if ((options & GMX_PR_SLICED) && relabel) {
-        p->ns = 4;   // measured best on RMAT-26 (profiles/): 2 XCD L2s share a slice
+        // measured (profiles/): one slice per XCD L2 from 2^24 vertices on (RMAT-26: 4.80 vs 5.08 ms), below that
+        // two XCDs share a slice (fewer (slice,row) pairs; RMAT-22: 0.265 vs 0.280 ms)
+        p->ns = g->V >= (1LL << 24) ? 8 : 4;
         const char* ev = getenv("GMX_PR_SLICES");
         if (ev && atoi(ev) >= 1 && atoi(ev) <= PR_MAX_SLICES) p->ns = atoi(ev);
     }

@@ -20,6 +20,9 @@ def load(path):
     return L
 
 
+ELEM = int(__import__("os").environ.get("AB_ELEM", "4"))
+
+
 def main():
     pa, pb = sys.argv[1], sys.argv[2]
     scale = int(sys.argv[3]) if len(sys.argv) > 3 else 26
@@ -30,7 +33,7 @@ def main():
     for name, L in libs:
         g, p = C.c_void_p(), C.c_void_p()
         assert L.gmx_graph_create_rmat(1 << scale, 16 << scale, 1997, 0.57, 0.19, 0.19, 1, 0, C.byref(g)) == 0, L.gmx_last_error()
-        assert L.gmx_pr_create(g, 4, 0, nranks, 7, C.byref(p)) == 0, L.gmx_last_error()
+        assert L.gmx_pr_create(g, ELEM, 0, nranks, 7, C.byref(p)) == 0, L.gmx_last_error()
         L.gmx_pr_reset(p, 0.85)
         state.append((name, L, g, p))
     d = C.c_double(0)
