@@ -329,3 +329,237 @@ extern "C" int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host,
     }
     return GMX_OK;
 }
+
+// ------------------------------------------------------------------ multi-GPU stepping object
+// replicated CSR, 1-D vertex ranges.  The levels that matter at scale are the
+// bottom-up ones (the few levels that reach most of the graph), and those partition by DESTINATION: rank k
+// looks for parents only for the unvisited vertices of its range and reports them as its slice of a
+// "found" bitmap -- V/8/N bytes to exchange per level (1 MiB at RMAT-26 on 8 GPUs), after which every rank
+// applies the whole bitmap to its dist[] replica and uses it as the next frontier.  Top-down levels (small
+// frontiers, little work) are simply run by every rank on the whole frontier: no exchange at all.  Every
+// rank sees the same frontier sizes, so all take the same direction decisions without talking.
+struct gmx_bfs {
+    gmx_graph* g = nullptr;
+    int rank = 0, nranks = 1;
+    int64_t V = 0, slice_words = 0, words = 0;   // bitmap words (64 vertices each): per rank, total (padded)
+    dbuf<int32_t> dist, q0, q1, deg;
+    dbuf<int64_t> off;
+    dbuf<char> scan_tmp;
+    size_t scan_bytes = 0;
+    dbuf<unsigned long long> bm[2];   // frontier / found, swapped after every bottom-up level
+    int fr = 0;                       // bm[fr] = frontier, bm[1 - fr] = found
+    dbuf<bfs_counters> ctr;
+    dbuf<unsigned long long> qcount;
+    int32_t level = 0;
+    int64_t cur_count = 0, reached = 0, explored = 0;
+    unsigned long long edges = 0;
+    bool frontier_is_bitmap = false, frontier_bm_valid = false, pending_bottom_up = false;
+    int32_t* cur_q = nullptr;
+    int32_t* next_q = nullptr;
+};
+
+// owned vertices [v_lo, v_hi), v_lo a multiple of 64: one found word per wave, no atomics
+__global__ void __launch_bounds__(BFS_THREADS)
+bfs_bottomup_part_kernel(const int32_t* __restrict__ r_begin, const int32_t* __restrict__ r_node_idx,
+                         int64_t v_lo, int64_t v_hi, int64_t V, const uint32_t* __restrict__ frontier_bm,
+                         const int32_t* __restrict__ dist, unsigned long long* __restrict__ found_bm,
+                         bfs_counters* __restrict__ ctr) {
+    int64_t t = v_lo + (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    unsigned long long inspected = 0;
+    for (; t < v_hi; t += stride) {   // v_hi - v_lo is a multiple of 64: whole waves
+        bool found = false;
+        if (t < V && dist[t] == INT_MAX) {
+            const int32_t b = r_begin[t], e = r_begin[t + 1];
+            for (int32_t i = b; i < e; i++) {
+                const int32_t w = r_node_idx[i];
+                inspected++;
+                if (frontier_bm[w >> 5] & (1u << (w & 31))) {
+                    found = true;
+                    break;
+                }
+            }
+        }
+        const unsigned long long m = __ballot(found);
+        if ((threadIdx.x & 63) == 0) found_bm[t >> 6] = m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) inspected += __shfl_down(inspected, off, 64);
+    if ((threadIdx.x & 63) == 0 && inspected) atomicAdd(&ctr->edges, inspected);
+}
+
+// every rank, whole bitmap: dist[v] = next_level where the bit is set; counts the new frontier
+__global__ void bfs_apply_found_kernel(const unsigned long long* __restrict__ found_bm, int64_t V, int32_t next_level,
+                                       int32_t* __restrict__ dist, bfs_counters* __restrict__ ctr) {
+    int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    const int64_t vend = (V + 63) / 64 * 64;
+    unsigned long long cnt = 0;
+    for (; v < vend; v += stride) {
+        const unsigned long long m = found_bm[v >> 6];
+        if (v < V && ((m >> (v & 63)) & 1ULL)) dist[v] = next_level;
+        if ((threadIdx.x & 63) == 0) cnt += (unsigned long long) __popcll(m);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&ctr->next_count, cnt);
+}
+
+extern "C" int gmx_bfs_create(gmx_graph_t* g, int rank, int nranks, gmx_bfs_t** out) {
+    GMX_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    GMX_REQUIRE(g, "graph is NULL");
+    GMX_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d / nranks %d", rank, nranks);
+    GMX_REQUIRE(nranks == 1 || g->has_reverse, "the partitioned traversal needs the reverse CSR");
+    gmx_bfs* b = new gmx_bfs();
+    b->g = g;
+    b->rank = rank;
+    b->nranks = nranks;
+    b->V = g->V;
+    const int64_t w = (g->V + 63) / 64;
+    b->slice_words = (w + nranks - 1) / nranks;
+    if (b->slice_words < 1) b->slice_words = 1;
+    b->words = b->slice_words * nranks;
+    const size_t V1 = (size_t) (g->V ? g->V : 1);
+    int st = GMX_OK;
+    if ((st = b->dist.alloc(V1)) || (st = b->q0.alloc(V1)) || (st = b->q1.alloc(V1)) || (st = b->deg.alloc(V1)) ||
+        (st = b->off.alloc(V1 + 2)) || (st = b->ctr.alloc(1)) || (st = b->qcount.alloc(1)) ||
+        (st = b->bm[0].alloc((size_t) b->words)) || (st = b->bm[1].alloc((size_t) b->words))) {
+        delete b;
+        return st;
+    }
+    if (rocprim::inclusive_scan(nullptr, b->scan_bytes, b->deg.p, b->off.p + 1, V1, rocprim::plus<int64_t>(), 0) != hipSuccess ||
+        (st = b->scan_tmp.alloc(b->scan_bytes))) {
+        delete b;
+        gmx_set_error("bfs: scan setup failed");
+        return st ? st : GMX_ERR_HIP;
+    }
+    *out = b;
+    return GMX_OK;
+}
+
+extern "C" int gmx_bfs_free(gmx_bfs_t* b) {
+    delete b;
+    return GMX_OK;
+}
+
+extern "C" int gmx_bfs_start(gmx_bfs_t* b, gmx_node_t root) {
+    GMX_REQUIRE(b, "bfs is NULL");
+    const int64_t V = b->V;
+    const bool root_ok = root >= 0 && root < V;
+    if (V > 0) hipLaunchKernelGGL(bfs_init_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, b->dist.p, V, root_ok ? root : -1);
+    GMX_HIP(hipMemset(b->bm[0].p, 0, sizeof(unsigned long long) * (size_t) b->words));
+    GMX_HIP(hipMemset(b->bm[1].p, 0, sizeof(unsigned long long) * (size_t) b->words));
+    b->level = 0;
+    b->cur_count = b->reached = root_ok ? 1 : 0;
+    b->explored = 0;
+    b->edges = 0;
+    b->frontier_is_bitmap = b->frontier_bm_valid = b->pending_bottom_up = false;
+    b->fr = 0;
+    b->cur_q = b->q0.p;
+    b->next_q = b->q1.p;
+    if (root_ok) GMX_HIP(hipMemcpy(b->q0.p, &root, sizeof(int32_t), hipMemcpyHostToDevice));
+    GMX_HIP(hipDeviceSynchronize());
+    return GMX_OK;
+}
+
+// frontier out-degrees -> off[], returns their sum (the same helper steps as in gmx_hop_dist)
+static int bfs_frontier_edges(gmx_bfs* b, int64_t* m_f) {
+    hipLaunchKernelGGL(bfs_degree_kernel, dim3(grid_for(b->cur_count)), dim3(BFS_THREADS), 0, 0, b->g->begin.p, b->cur_q, b->cur_count, b->deg.p);
+    size_t tb = b->scan_bytes;
+    GMX_HIP(rocprim::inclusive_scan(b->scan_tmp.p, tb, b->deg.p, b->off.p + 1, (size_t) b->cur_count, rocprim::plus<int64_t>(), 0));
+    GMX_HIP(hipMemsetAsync(b->off.p, 0, sizeof(int64_t), 0));
+    GMX_HIP(hipMemcpy(m_f, b->off.p + b->cur_count, sizeof(int64_t), hipMemcpyDeviceToHost));
+    return GMX_OK;
+}
+
+extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
+    GMX_REQUIRE(b && needs_exchange, "NULL argument");
+    *needs_exchange = 0;
+    b->pending_bottom_up = false;
+    if (b->cur_count <= 0) return GMX_OK;
+    gmx_graph* g = b->g;
+    const int64_t V = b->V;
+    bfs_counters zero = {0, b->edges};
+    GMX_HIP(hipMemcpy(b->ctr.p, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    int64_t m_f = 0;
+    bool bottom_up;
+    if (b->frontier_is_bitmap) bottom_up = b->cur_count > V / 24;
+    else {
+        GMX_CHECK(bfs_frontier_edges(b, &m_f));
+        bottom_up = g->has_reverse && (b->cur_count > V / 20 || m_f > (g->E - b->explored) / 14);
+        b->explored += m_f;
+    }
+    if (bottom_up) {
+        if (!b->frontier_bm_valid)   // first bottom-up level after queue levels: frontier = {v : dist[v] == level}
+            hipLaunchKernelGGL(bfs_level_bitmap_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
+                               (const int32_t*) b->dist.p, V, b->level, b->bm[b->fr].p);
+        const int64_t v_lo = (int64_t) b->rank * b->slice_words * 64;
+        const int64_t v_hi = v_lo + b->slice_words * 64;
+        hipLaunchKernelGGL(bfs_bottomup_part_kernel, dim3(grid_for(v_hi - v_lo, BFS_THREADS, 256 * 32)), dim3(BFS_THREADS), 0, 0,
+                           g->r_begin.p, g->r_node_idx.p, v_lo, v_hi, V, (const uint32_t*) b->bm[b->fr].p,
+                           (const int32_t*) b->dist.p, b->bm[1 - b->fr].p, b->ctr.p);
+        b->pending_bottom_up = true;
+        *needs_exchange = b->nranks > 1 ? 1 : 0;
+    } else {
+        if (b->frontier_is_bitmap) {   // back from bottom-up: rebuild the queue and its edge offsets
+            GMX_HIP(hipMemsetAsync(b->qcount.p, 0, sizeof(unsigned long long), 0));
+            hipLaunchKernelGGL(bfs_level_queue_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
+                               (const int32_t*) b->dist.p, V, b->level, b->cur_q, b->qcount.p);
+            b->frontier_is_bitmap = false;
+            GMX_CHECK(bfs_frontier_edges(b, &m_f));
+            b->explored += m_f;
+        }
+        b->frontier_bm_valid = false;
+        const int64_t nb = (b->cur_count + m_f + BFS_ITEMS - 1) / BFS_ITEMS;
+        if (nb > 0)
+            hipLaunchKernelGGL(bfs_topdown_kernel, dim3((unsigned) nb), dim3(BFS_THREADS), 0, 0,
+                               g->begin.p, g->node_idx.p, b->cur_q, b->cur_count, b->off.p, m_f, b->level, b->dist.p, b->next_q, b->ctr.p);
+        int32_t* t = b->cur_q;
+        b->cur_q = b->next_q;
+        b->next_q = t;
+    }
+    GMX_HIP(hipGetLastError());
+    return GMX_OK;
+}
+
+extern "C" int gmx_bfs_found_bitmap(gmx_bfs_t* b, void** words, int64_t* total_words, int64_t* slice_offset, int64_t* slice_words) {
+    GMX_REQUIRE(b && words && total_words && slice_offset && slice_words, "NULL argument");
+    *words = b->bm[1 - b->fr].p;
+    *total_words = b->words;
+    *slice_offset = (int64_t) b->rank * b->slice_words;
+    *slice_words = b->slice_words;
+    return GMX_OK;
+}
+
+extern "C" int gmx_bfs_step_end(gmx_bfs_t* b, int64_t* next_count) {
+    GMX_REQUIRE(b && next_count, "NULL argument");
+    *next_count = 0;
+    if (b->cur_count <= 0) return GMX_OK;
+    if (b->pending_bottom_up) {
+        hipLaunchKernelGGL(bfs_apply_found_kernel, dim3(grid_for(b->V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
+                           (const unsigned long long*) b->bm[1 - b->fr].p, b->V, b->level + 1, b->dist.p, b->ctr.p);
+        GMX_HIP(hipGetLastError());
+        b->fr = 1 - b->fr;   // what was found is the next frontier
+        b->frontier_is_bitmap = b->frontier_bm_valid = true;
+        b->pending_bottom_up = false;
+    }
+    bfs_counters h;
+    GMX_HIP(hipMemcpy(&h, b->ctr.p, sizeof(h), hipMemcpyDeviceToHost));
+    b->cur_count = (int64_t) h.next_count;
+    b->edges = h.edges;
+    b->reached += b->cur_count;
+    b->level++;
+    *next_count = b->cur_count;
+    return GMX_OK;
+}
+
+extern "C" int gmx_bfs_download(gmx_bfs_t* b, int32_t* dist_host, gmx_stats_t* stats) {
+    GMX_REQUIRE(b && dist_host, "NULL argument");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (b->V > 0) GMX_HIP(hipMemcpy(dist_host, b->dist.p, sizeof(int32_t) * (size_t) b->V, hipMemcpyDeviceToHost));
+    if (stats) {
+        stats->iterations = b->level;
+        stats->edges_examined = (int64_t) b->edges;   // this rank's share in the partitioned levels
+        stats->vertices_reached = b->reached;
+    }
+    return GMX_OK;
+}

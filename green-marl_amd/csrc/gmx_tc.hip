@@ -33,6 +33,14 @@ __device__ __forceinline__ bool tc_contains(const int32_t* __restrict__ a, int32
     return p < hi && a[p] == x;
 }
 
+// Multi-GPU: the edge slots are dealt to `nparts` parts in blocks of 2^TC_DEAL_SHIFT slots, round-robin
+// (slot work varies by orders of magnitude with the degrees involved; a contiguous split would leave the
+// hub rows to one rank).  Local index i of part `part` <-> global slot:
+#define TC_DEAL_SHIFT 12
+__device__ __forceinline__ int64_t tc_slot_of(int64_t i, int part, int nparts) {
+    return ((((i >> TC_DEAL_SHIFT) * nparts) + part) << TC_DEAL_SHIFT) | (i & ((1 << TC_DEAL_SHIFT) - 1));
+}
+
 struct tc_pair { int32_t tb, te, rb, re; };  // tail [tb,te) in node_idx, in-row [rb,re) in r_node_idx (values > u)
 
 // walk `short side`, search `long side`; lanes = 1 (thread) or 64 (wave)
@@ -62,12 +70,15 @@ __device__ __forceinline__ unsigned long long tc_intersect(const int32_t* __rest
 __global__ void __launch_bounds__(TC_THREADS)
 tc_slots_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx,
                 const int32_t* __restrict__ r_begin, const int32_t* __restrict__ r_node_idx,
-                int64_t V, int64_t E, tc_pair* __restrict__ big, unsigned long long* __restrict__ nbig,
+                int64_t V, int64_t E, int64_t nlocal, int part, int nparts,
+                tc_pair* __restrict__ big, unsigned long long* __restrict__ nbig,
                 unsigned long long* __restrict__ total) {
-    int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t) gridDim.x * blockDim.x;
     unsigned long long c = 0;
-    for (; e < E; e += stride) {
+    for (; i < nlocal; i += stride) {
+        const int64_t e = tc_slot_of(i, part, nparts);
+        if (e >= E) continue;
         // v = row of slot e
         int64_t lo = 0, hi = V;
         while (hi - lo > 1) {
@@ -109,12 +120,14 @@ tc_big_kernel(const int32_t* __restrict__ node_idx, const int32_t* __restrict__ 
 // slot (v,u) strides over the tail and binary searches u in the forward row of w.
 __global__ void __launch_bounds__(TC_THREADS)
 tc_forward_only_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx,
-                       int64_t V, int64_t E, unsigned long long* __restrict__ total) {
+                       int64_t V, int64_t E, int64_t nlocal, int part, int nparts, unsigned long long* __restrict__ total) {
     const int lane = threadIdx.x & 63;
-    int64_t e = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    int64_t i = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t) gridDim.x * blockDim.x) >> 6;
     unsigned long long c = 0;
-    for (; e < E; e += nwaves) {
+    for (; i < nlocal; i += nwaves) {
+        const int64_t e = tc_slot_of(i, part, nparts);
+        if (e >= E) continue;
         int64_t lo = 0, hi = V;
         while (hi - lo > 1) {
             int64_t mid = (lo + hi) >> 1;
@@ -135,10 +148,20 @@ tc_forward_only_kernel(const int32_t* __restrict__ begin, const int32_t* __restr
 }
 
 extern "C" int gmx_triangle_counting(gmx_graph_t* g, int64_t* count, gmx_stats_t* stats) {
+    return gmx_triangle_counting_part(g, 0, 1, count, stats);
+}
+
+extern "C" int gmx_triangle_counting_part(gmx_graph_t* g, int part, int nparts, int64_t* count, gmx_stats_t* stats) {
     GMX_REQUIRE(g && count, "NULL argument");
+    GMX_REQUIRE(nparts >= 1 && part >= 0 && part < nparts, "bad part %d / nparts %d", part, nparts);
     if (stats) memset(stats, 0, sizeof(*stats));
     *count = 0;
     if (g->E == 0) return GMX_OK;
+    // local slot indices of this part: whole deal blocks (slots past E are skipped in the kernels)
+    const int64_t deal = (int64_t) 1 << TC_DEAL_SHIFT;
+    const int64_t nblocks = (g->E + deal - 1) / deal;
+    const int64_t nlocal = ((nblocks - part + nparts - 1) / nparts) * deal;
+    if (nlocal <= 0) return GMX_OK;
     dbuf<unsigned long long> ctr;   // [0] total, [1] nbig
     GMX_CHECK(ctr.alloc(2));
     GMX_HIP(hipMemset(ctr.p, 0, 2 * sizeof(unsigned long long)));
@@ -146,13 +169,13 @@ extern "C" int gmx_triangle_counting(gmx_graph_t* g, int64_t* count, gmx_stats_t
     GMX_HIP(hipEventCreate(&ev0));
     GMX_HIP(hipEventCreate(&ev1));
     GMX_HIP(hipEventRecord(ev0, 0));
-    int64_t blocks = (g->E + TC_THREADS - 1) / TC_THREADS;
+    int64_t blocks = (nlocal + TC_THREADS - 1) / TC_THREADS;
     if (g->has_reverse) {
         dbuf<tc_pair> big;
-        GMX_CHECK(big.alloc((size_t) g->E));
+        GMX_CHECK(big.alloc((size_t) nlocal));
         if (blocks > 256 * 64) blocks = 256 * 64;
         hipLaunchKernelGGL(tc_slots_kernel, dim3((unsigned) blocks), dim3(TC_THREADS), 0, 0,
-                           g->begin.p, g->node_idx.p, g->r_begin.p, g->r_node_idx.p, g->V, g->E, big.p, ctr.p + 1, ctr.p);
+                           g->begin.p, g->node_idx.p, g->r_begin.p, g->r_node_idx.p, g->V, g->E, nlocal, part, nparts, big.p, ctr.p + 1, ctr.p);
         GMX_HIP(hipGetLastError());
         unsigned long long h[2];
         GMX_HIP(hipMemcpy(h, ctr.p, sizeof(h), hipMemcpyDeviceToHost));
@@ -165,10 +188,10 @@ extern "C" int gmx_triangle_counting(gmx_graph_t* g, int64_t* count, gmx_stats_t
         }
         GMX_HIP(hipDeviceSynchronize());
     } else {
-        int64_t wb = (g->E * 64 + TC_THREADS - 1) / TC_THREADS;
+        int64_t wb = (nlocal * 64 + TC_THREADS - 1) / TC_THREADS;
         if (wb > 256 * 64) wb = 256 * 64;
         hipLaunchKernelGGL(tc_forward_only_kernel, dim3((unsigned) wb), dim3(TC_THREADS), 0, 0,
-                           g->begin.p, g->node_idx.p, g->V, g->E, ctr.p);
+                           g->begin.p, g->node_idx.p, g->V, g->E, nlocal, part, nparts, ctr.p);
         GMX_HIP(hipGetLastError());
     }
     GMX_HIP(hipEventRecord(ev1, 0));

@@ -43,7 +43,9 @@ EXPORTS = [
     "gmx_last_error", "gmx_device_count", "gmx_set_device", "gmx_device_info",
     "gmx_graph_upload", "gmx_graph_from_edges", "gmx_graph_create_rmat", "gmx_graph_free", "gmx_graph_symmetrize",
     "gmx_graph_num_nodes", "gmx_graph_num_edges", "gmx_graph_download",
-    "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_triangle_counting",
+    "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_triangle_counting", "gmx_triangle_counting_part",
+    "gmx_bfs_create", "gmx_bfs_free", "gmx_bfs_start", "gmx_bfs_step_begin", "gmx_bfs_found_bitmap", "gmx_bfs_step_end",
+    "gmx_bfs_download",
     "gmx_pr_create", "gmx_pr_free", "gmx_pr_reset", "gmx_pr_step", "gmx_pr_contrib_slice",
     "gmx_pr_contrib_full", "gmx_pr_exchange_count", "gmx_pr_diff_ptr", "gmx_pr_diff", "gmx_pr_download", "gmx_pr_work",
     "gmx_pr_set_chunks", "gmx_pr_num_chunks", "gmx_pr_chunk_range", "gmx_pr_step_chunk", "gmx_pr_contrib_next_full",
@@ -90,6 +92,14 @@ def lib():
         L.gmx_pagerank_f32.argtypes = [vp, C.c_float, C.c_float, i32, vp, C.POINTER(Stats)]
         L.gmx_hop_dist.argtypes = [vp, i32, vp, C.POINTER(Stats)]
         L.gmx_triangle_counting.argtypes = [vp, C.POINTER(i64), C.POINTER(Stats)]
+        L.gmx_triangle_counting_part.argtypes = [vp, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(Stats)]
+        L.gmx_bfs_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+        L.gmx_bfs_free.argtypes = [vp]
+        L.gmx_bfs_start.argtypes = [vp, i32]
+        L.gmx_bfs_step_begin.argtypes = [vp, C.POINTER(C.c_int)]
+        L.gmx_bfs_found_bitmap.argtypes = [vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+        L.gmx_bfs_step_end.argtypes = [vp, C.POINTER(i64)]
+        L.gmx_bfs_download.argtypes = [vp, vp, C.POINTER(Stats)]
         L.gmx_pr_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(vp)]
         L.gmx_pr_free.argtypes = [vp]
         L.gmx_pr_reset.argtypes = [vp, C.c_double]
@@ -252,11 +262,11 @@ class Graph:
         _ck(lib().gmx_hop_dist(self._h, root, dist.ctypes.data, C.byref(st)))
         return dist, st.as_dict()
 
-    def triangle_counting(self):
-        """triangle_counting(G) -- returns (T, stats)."""
+    def triangle_counting(self, part=0, nparts=1):
+        """triangle_counting(G) -- returns (T, stats); with nparts > 1 the share of one part of the edge slots."""
         t = C.c_int64(0)
         st = Stats()
-        _ck(lib().gmx_triangle_counting(self._h, C.byref(t), C.byref(st)))
+        _ck(lib().gmx_triangle_counting_part(self._h, part, nparts, C.byref(t), C.byref(st)))
         return t.value, st.as_dict()
 
 
@@ -271,6 +281,54 @@ class DevArray:
     def __init__(self, ptr, count, typestr):
         self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False),
                                          "version": 2, "strides": None}
+
+
+class BfsState:
+    """Device-resident hop_dist stepping state (gmx_bfs_*) for one rank of nranks (replicated graph)."""
+
+    def __init__(self, graph, rank=0, nranks=1):
+        self.graph = graph
+        self.rank, self.nranks = rank, nranks
+        h = C.c_void_p()
+        _ck(lib().gmx_bfs_create(graph._h, rank, nranks, C.byref(h)))
+        self._h = h
+
+    def start(self, root):
+        _ck(lib().gmx_bfs_start(self._h, int(root)))
+
+    def step_begin(self):
+        """Runs the local part of the next level; True if the found-bitmap slices have to be exchanged."""
+        need = C.c_int(0)
+        _ck(lib().gmx_bfs_step_begin(self._h, C.byref(need)))
+        return bool(need.value)
+
+    def found_bitmap(self):
+        """(whole bitmap as DevArray of int64 words, slice offset, slice length) -- words of 64 vertices."""
+        p, tot, off, n = C.c_void_p(), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _ck(lib().gmx_bfs_found_bitmap(self._h, C.byref(p), C.byref(tot), C.byref(off), C.byref(n)))
+        return DevArray(p.value, tot.value, "<i8"), off.value, n.value
+
+    def step_end(self):
+        n = C.c_int64(0)
+        _ck(lib().gmx_bfs_step_end(self._h, C.byref(n)))
+        return n.value
+
+    def download(self):
+        out = np.zeros(max(self.graph.V, 1), np.int32)[:self.graph.V].copy()
+        st = Stats()
+        _ck(lib().gmx_bfs_download(self._h, out.ctypes.data, C.byref(st)))
+        return out, st.as_dict()
+
+    def free(self):
+        if self._h:
+            lib().gmx_bfs_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class PageRankState:

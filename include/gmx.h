@@ -122,8 +122,27 @@ int gmx_pagerank_f32(gmx_graph_t* g, float e, float d, int32_t max_iter,
 /* hop_dist(G, G_dist, root): BFS depth along out-edges, INT_MAX = unreached. */
 int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host, gmx_stats_t* stats);
 
+/* hop_dist over several GPUs: replicated CSR, every rank runs gmx_bfs_step_begin /
+ * [exchange] / gmx_bfs_step_end per level until the frontier is empty.  step_begin runs a top-down level
+ * entirely (needs_exchange = 0: every rank expands the whole, small frontier) or the rank's share of a
+ * bottom-up level, writing its slice [slice_offset, slice_offset + slice_words) of the found bitmap
+ * (64 vertices per word; needs_exchange = 1 when nranks > 1: all-gather the slices in place).  step_end
+ * applies the bitmap to the rank's dist[] replica and returns the next frontier's size -- the same number on
+ * every rank, so the ranks agree on direction and termination without further communication. */
+typedef struct gmx_bfs gmx_bfs_t;
+int gmx_bfs_create(gmx_graph_t* g, int rank, int nranks, gmx_bfs_t** out);
+int gmx_bfs_free(gmx_bfs_t* b);
+int gmx_bfs_start(gmx_bfs_t* b, gmx_node_t root);
+int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange);
+int gmx_bfs_found_bitmap(gmx_bfs_t* b, void** words, int64_t* total_words, int64_t* slice_offset, int64_t* slice_words);
+int gmx_bfs_step_end(gmx_bfs_t* b, int64_t* next_count);
+int gmx_bfs_download(gmx_bfs_t* b, int32_t* dist_host, gmx_stats_t* stats);
+
 /* triangle_counting(G) with the emitted multiplicity rule. */
 int gmx_triangle_counting(gmx_graph_t* g, int64_t* count, gmx_stats_t* stats);
+/* Multi-GPU form (replicated CSR, final all-reduce of int64): the count contributed by part
+ * `part` of `nparts` of the edge slots (dealt in blocks, round-robin); the parts add up to the full count. */
+int gmx_triangle_counting_part(gmx_graph_t* g, int part, int nparts, int64_t* count, gmx_stats_t* stats);
 
 /* ---- device-resident PageRank stepping (bench.py / multi-GPU driver) ----
  * A gmx_pr_t owns the rows [row_lo,row_hi) of the (internally relabelled) graph

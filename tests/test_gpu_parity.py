@@ -316,6 +316,79 @@ def test_peer_push_exchange_between_processes(gmx, world, chunks, elem):
     assert "-> OK" in outs[0], outs[0]
 
 
+def _bfs_ranks_in_one_process(gmx, og, root, nranks):
+    """N rank states of the partitioned hop_dist side by side; device copies stand in for the all-gather."""
+    import torch
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    states = [gmx.BfsState(g, r, nranks) for r in range(nranks)]
+    for s in states:
+        s.start(root)
+    levels = exchanges = 0
+    while True:
+        needs = [s.step_begin() for s in states]
+        assert len(set(needs)) == 1                       # every rank takes the same direction
+        if needs[0]:
+            views = []
+            for s in states:
+                words, off, n = s.found_bitmap()
+                views.append((torch.as_tensor(words, device="cuda"), off, n))
+            for dst, _, _ in views:
+                for src, off, n in views:
+                    if dst is not src:
+                        dst[off:off + n].copy_(src[off:off + n])
+            torch.cuda.synchronize()
+            exchanges += 1
+        counts = [s.step_end() for s in states]
+        assert len(set(counts)) == 1                      # ... and sees the same next frontier
+        if counts[0] == 0:
+            break
+        levels += 1
+    outs = [s.download()[0] for s in states]
+    for s in states:
+        s.free()
+    g.free()
+    return outs, levels, exchanges
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 3, 8])
+def test_hop_dist_partitioned_ranks_in_one_process(gmx, nranks):
+    """gmx_bfs_*: replicated top-down levels, bottom-up levels partitioned by destination range with a
+    found-bitmap slice per rank.  dist[] must be bit-exact on every rank."""
+    for scale, permute, root in [(16, False, 0), (14, True, 5), (10, False, 3)]:
+        og = po.rmat_graph(scale, permute=permute)
+        want = po.hop_dist(og, root)[0]
+        outs, levels, exchanges = _bfs_ranks_in_one_process(gmx, og, root, nranks)
+        for o in outs:
+            assert np.array_equal(o, want)
+        if scale == 16 and nranks > 1:
+            assert exchanges >= 1                           # the hub-rooted traversal does go bottom-up
+    # shapes the direction rule treats differently: a chain (always top-down), a star (one huge level),
+    # an unreachable root and a root outside the graph
+    n = 3000
+    chain = po.graph_from_edges(n, np.arange(n - 1, dtype=np.int32), np.arange(1, n, dtype=np.int32))
+    star = po.graph_from_edges(n, np.zeros(n - 1, np.int32), np.arange(1, n, dtype=np.int32))
+    for og, root in [(chain, 0), (chain, n - 1), (star, 0), (star, 7), (star, n + 5)]:
+        want = po.hop_dist(og, root)[0] if root < n else np.full(n, INT_MAX, np.int32)
+        outs, _, _ = _bfs_ranks_in_one_process(gmx, og, root, nranks)
+        for o in outs:
+            assert np.array_equal(o, want)
+
+
+@pytest.mark.parametrize("nparts", [2, 3, 8])
+def test_triangle_counting_parts_add_up(gmx, nparts):
+    og = po.rmat_graph(14, permute=True)
+    for graph in (og, po.symmetrize(og)):
+        g = gmx.Graph.upload(graph.begin, graph.node_idx, graph.r_begin, graph.r_node_idx)
+        full = g.triangle_counting()[0]
+        assert full == po.triangle_counting(graph)
+        assert sum(g.triangle_counting(p, nparts)[0] for p in range(nparts)) == full
+        g.free()
+    # forward-only form (no reverse CSR on the device)
+    g = gmx.Graph.upload(og.begin, og.node_idx, None, None, flags=gmx.GMX_GRAPH_NO_REVERSE)
+    assert sum(g.triangle_counting(p, nparts)[0] for p in range(nparts)) == po.triangle_counting(og)
+    g.free()
+
+
 def test_dist_engine_world1_and_kernel_timing(gmx):
     from dist_pagerank import DistPageRank, GmxEngine
     og = po.rmat_graph(14, permute=True)
