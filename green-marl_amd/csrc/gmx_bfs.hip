@@ -13,7 +13,9 @@
 //                queue built with __ballot-aggregated appends;
 //   * bottom-up: when the frontier exceeds 5 % of V (RRD_THRESHOLD, gm_bfs_template.h:359),
 //                every unvisited vertex scans its in-row for a parent whose bit is set in the
-//                frontier bitmap (V/8 bytes: fits L2) and stops at the first hit.
+//                frontier bitmap (V/8 bytes: fits L2) and stops at the first hit; the vertices found
+//                are reported as a bitmap (one ballot per wave), applied to dist[] and reused as the
+//                next level's frontier -- and, with several GPUs, exchanged slice by slice.
 // Integer only: bit-exact against the CPU result by construction.
 #include "gmx_internal.h"
 
@@ -123,38 +125,6 @@ __global__ void bfs_level_bitmap_kernel(const int32_t* __restrict__ dist, int64_
     }
 }
 
-// one thread per vertex; unvisited vertices look for a parent in the frontier bitmap
-__global__ void __launch_bounds__(BFS_THREADS)
-bfs_bottomup_kernel(const int32_t* __restrict__ r_begin, const int32_t* __restrict__ r_node_idx, int64_t V,
-                    int32_t level, const uint32_t* __restrict__ frontier_bm,
-                    int32_t* __restrict__ dist, bfs_counters* __restrict__ ctr) {
-    int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t stride = (int64_t) gridDim.x * blockDim.x;
-    unsigned long long inspected = 0, found_cnt = 0;
-    for (; t < V; t += stride) {
-        if (dist[t] != INT_MAX) continue;
-        int32_t b = r_begin[t], e = r_begin[t + 1];
-        for (int32_t i = b; i < e; i++) {
-            int32_t w = r_node_idx[i];
-            inspected++;
-            if (frontier_bm[w >> 5] & (1u << (w & 31))) {
-                dist[t] = level + 1;
-                found_cnt++;
-                break;
-            }
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        inspected += __shfl_down(inspected, off, 64);
-        found_cnt += __shfl_down(found_cnt, off, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (inspected) atomicAdd(&ctr->edges, inspected);
-        if (found_cnt) atomicAdd(&ctr->next_count, found_cnt);
-    }
-}
-
 // queue of a level straight from dist[] (ballot-aggregated append)
 __global__ void bfs_level_queue_kernel(const int32_t* __restrict__ dist, int64_t V, int32_t level,
                                        int32_t* __restrict__ q, unsigned long long* __restrict__ qcount) {
@@ -195,142 +165,7 @@ static int grid_for(int64_t n, int block = BFS_THREADS, int max_blocks = 256 * 8
     return (int) b;
 }
 
-extern "C" int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host, gmx_stats_t* stats) {
-    GMX_REQUIRE(g && dist_host, "NULL argument");
-    if (stats) memset(stats, 0, sizeof(*stats));
-    const int64_t V = g->V;
-    if (V == 0) return GMX_OK;
-    const bool root_ok = root >= 0 && root < V;   // a root outside the graph reaches nothing
-
-    dbuf<int32_t> dist, q0, q1;
-    dbuf<unsigned long long> bm;
-    dbuf<bfs_counters> ctr;
-    dbuf<unsigned long long> qcount;
-    dbuf<int32_t> deg;
-    dbuf<int64_t> off;
-    dbuf<char> scan_tmp;
-    size_t scan_bytes = 0;
-    const size_t bmw = (size_t) ((V + 63) / 64);
-    GMX_CHECK(dist.alloc((size_t) V));
-    GMX_CHECK(q0.alloc((size_t) V));
-    GMX_CHECK(q1.alloc((size_t) V));
-    GMX_CHECK(ctr.alloc(1));
-    GMX_CHECK(qcount.alloc(1));
-    GMX_CHECK(deg.alloc((size_t) V));
-    GMX_CHECK(off.alloc((size_t) V + 2));
-    GMX_HIP(rocprim::inclusive_scan(nullptr, scan_bytes, deg.p, off.p + 1, (size_t) V, rocprim::plus<int64_t>(), 0));
-    GMX_CHECK(scan_tmp.alloc(scan_bytes));
-    const bool can_bottom_up = g->has_reverse;
-    if (can_bottom_up) GMX_CHECK(bm.alloc(bmw));
-
-    hipEvent_t ev0, ev1;
-    GMX_HIP(hipEventCreate(&ev0));
-    GMX_HIP(hipEventCreate(&ev1));
-    GMX_HIP(hipEventRecord(ev0, 0));
-
-    hipLaunchKernelGGL(bfs_init_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, dist.p, V, root_ok ? root : -1);
-    int32_t level = 0;
-    int64_t cur_count = 0, reached = 0;
-    unsigned long long edges = 0;
-    if (root_ok) {
-        GMX_HIP(hipMemcpy(q0.p, &root, sizeof(int32_t), hipMemcpyHostToDevice));
-        cur_count = 1;
-        reached = 1;
-    }
-    int32_t* cur_q = q0.p;
-    int32_t* next_q = q1.p;
-    bool frontier_is_bitmap = false;     // true: the last level ran bottom-up (no queue exists for the frontier)
-    const int64_t bu_threshold = V / 20; // RRD_THRESHOLD = 0.05 (gm_bfs_template.h:359)
-    int64_t explored = 0;                // out-edges of the frontiers expanded so far
-
-    while (cur_count > 0) {
-        bfs_counters zero = {0, edges};
-        GMX_HIP(hipMemcpy(ctr.p, &zero, sizeof(zero), hipMemcpyHostToDevice));
-        // Direction choice (Beamer's rule with the reference's 5 % vertex threshold as a second trigger,
-        // gm_bfs_template.h:359-415): a queue frontier goes bottom-up when its out-edges exceed 1/14 of the
-        // edges not yet explored; a bitmap frontier returns to the queue when it shrinks below V/24.
-        int64_t m_f = 0;
-        bool bottom_up;
-        if (frontier_is_bitmap) bottom_up = cur_count > V / 24;
-        else {
-            hipLaunchKernelGGL(bfs_degree_kernel, dim3(grid_for(cur_count)), dim3(BFS_THREADS), 0, 0, g->begin.p, cur_q, cur_count, deg.p);
-            size_t tb = scan_bytes;
-            GMX_HIP(rocprim::inclusive_scan(scan_tmp.p, tb, deg.p, off.p + 1, (size_t) cur_count, rocprim::plus<int64_t>(), 0));
-            GMX_HIP(hipMemsetAsync(off.p, 0, sizeof(int64_t), 0));
-            GMX_HIP(hipMemcpy(&m_f, off.p + cur_count, sizeof(int64_t), hipMemcpyDeviceToHost));
-            const int64_t unexplored = g->E - explored;
-            bottom_up = can_bottom_up && (cur_count > bu_threshold || m_f > unexplored / 14);
-            explored += m_f;
-        }
-        if (bottom_up) {
-            // the frontier of this level is {v : dist[v] == level}, whichever direction produced it
-            hipLaunchKernelGGL(bfs_level_bitmap_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
-                               (const int32_t*) dist.p, V, level, bm.p);
-            hipLaunchKernelGGL(bfs_bottomup_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 32)), dim3(BFS_THREADS), 0, 0,
-                               g->r_begin.p, g->r_node_idx.p, V, level, (const uint32_t*) bm.p, dist.p, ctr.p);
-            frontier_is_bitmap = true;
-        } else {
-            if (frontier_is_bitmap) {  // came back from bottom-up: rebuild the queue, then its edge offsets
-                GMX_HIP(hipMemsetAsync(qcount.p, 0, sizeof(unsigned long long), 0));
-                hipLaunchKernelGGL(bfs_level_queue_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
-                                   (const int32_t*) dist.p, V, level, cur_q, qcount.p);
-                frontier_is_bitmap = false;
-                hipLaunchKernelGGL(bfs_degree_kernel, dim3(grid_for(cur_count)), dim3(BFS_THREADS), 0, 0, g->begin.p, cur_q, cur_count, deg.p);
-                size_t tb = scan_bytes;
-                GMX_HIP(rocprim::inclusive_scan(scan_tmp.p, tb, deg.p, off.p + 1, (size_t) cur_count, rocprim::plus<int64_t>(), 0));
-                GMX_HIP(hipMemsetAsync(off.p, 0, sizeof(int64_t), 0));
-                GMX_HIP(hipMemcpy(&m_f, off.p + cur_count, sizeof(int64_t), hipMemcpyDeviceToHost));
-                explored += m_f;
-            }
-            int64_t nb = (cur_count + m_f + BFS_ITEMS - 1) / BFS_ITEMS;
-            if (nb > 0)
-                hipLaunchKernelGGL(bfs_topdown_kernel, dim3((unsigned) nb), dim3(BFS_THREADS), 0, 0,
-                                   g->begin.p, g->node_idx.p, cur_q, cur_count, off.p, m_f, level, dist.p, next_q, ctr.p);
-            int32_t* t = cur_q; cur_q = next_q; next_q = t;
-        }
-        GMX_HIP(hipGetLastError());
-        bfs_counters h;
-        GMX_HIP(hipMemcpy(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost));
-        cur_count = (int64_t) h.next_count;
-        edges = h.edges;
-        reached += cur_count;
-        level++;
-    }
-    GMX_HIP(hipEventRecord(ev1, 0));
-    GMX_HIP(hipEventSynchronize(ev1));
-    float ms = 0;
-    (void) hipEventElapsedTime(&ms, ev0, ev1);
-    unsigned long long edges_reached = 0;
-    if (stats) {   // statistics only, outside the timed traversal
-        GMX_HIP(hipMemset(qcount.p, 0, sizeof(unsigned long long)));
-        hipLaunchKernelGGL(bfs_edges_reached_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, (const int32_t*) dist.p, g->begin.p, V, qcount.p);
-        GMX_HIP(hipMemcpy(&edges_reached, qcount.p, sizeof(edges_reached), hipMemcpyDeviceToHost));
-    }
-    hipEvent_t c0, c1;
-    (void) hipEventCreate(&c0);
-    (void) hipEventCreate(&c1);
-    (void) hipEventRecord(c0, 0);
-    GMX_HIP(hipMemcpy(dist_host, dist.p, sizeof(int32_t) * (size_t) V, hipMemcpyDeviceToHost));
-    (void) hipEventRecord(c1, 0);
-    (void) hipEventSynchronize(c1);
-    float cms = 0;
-    (void) hipEventElapsedTime(&cms, c0, c1);
-    (void) hipEventDestroy(c0);
-    (void) hipEventDestroy(c1);
-    (void) hipEventDestroy(ev0);
-    (void) hipEventDestroy(ev1);
-    if (stats) {
-        stats->iterations = level;
-        stats->kernel_ms = ms;
-        stats->d2h_ms = cms;
-        stats->edges_examined = (int64_t) edges;
-        stats->vertices_reached = reached;
-        stats->edges_reached = (int64_t) edges_reached;
-    }
-    return GMX_OK;
-}
-
-// ------------------------------------------------------------------ multi-GPU stepping object
+// ------------------------------------------------------------------ the traversal as a stepping object (1..N ranks)
 // replicated CSR, 1-D vertex ranges.  The levels that matter at scale are the
 // bottom-up ones (the few levels that reach most of the graph), and those partition by DESTINATION: rank k
 // looks for parents only for the unvisited vertices of its range and reports them as its slice of a
@@ -562,4 +397,52 @@ extern "C" int gmx_bfs_download(gmx_bfs_t* b, int32_t* dist_host, gmx_stats_t* s
         stats->vertices_reached = b->reached;
     }
     return GMX_OK;
+}
+
+// The whole-kernel entry (what the generated hop_dist() calls): the stepping object with a single rank.
+extern "C" int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host, gmx_stats_t* stats) {
+    GMX_REQUIRE(g && dist_host, "NULL argument");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (g->V == 0) return GMX_OK;
+    gmx_bfs_t* b = nullptr;
+    GMX_CHECK(gmx_bfs_create(g, 0, 1, &b));
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (hipEvent_t& e : ev) (void) hipEventCreate(&e);
+    int st = GMX_OK;
+    (void) hipEventRecord(ev[0], 0);
+    if ((st = gmx_bfs_start(b, root)) == GMX_OK) {
+        int64_t next = 0;
+        int need = 0;
+        do {
+            if ((st = gmx_bfs_step_begin(b, &need)) != GMX_OK) break;
+            if ((st = gmx_bfs_step_end(b, &next)) != GMX_OK) break;
+        } while (next > 0);
+    }
+    (void) hipEventRecord(ev[1], 0);
+    (void) hipEventSynchronize(ev[1]);
+    unsigned long long edges_reached = 0;
+    if (st == GMX_OK && stats) {   // statistics only, outside the timed traversal
+        if (hipMemset(b->qcount.p, 0, sizeof(unsigned long long)) == hipSuccess) {
+            hipLaunchKernelGGL(bfs_edges_reached_kernel, dim3(grid_for(g->V)), dim3(BFS_THREADS), 0, 0, (const int32_t*) b->dist.p, g->begin.p, g->V, b->qcount.p);
+            (void) hipMemcpy(&edges_reached, b->qcount.p, sizeof(edges_reached), hipMemcpyDeviceToHost);
+        }
+    }
+    if (st == GMX_OK) {
+        (void) hipEventRecord(ev[2], 0);
+        st = gmx_bfs_download(b, dist_host, stats);
+        (void) hipEventRecord(ev[3], 0);
+        (void) hipEventSynchronize(ev[3]);
+        if (st == GMX_OK && stats) {
+            float ms = 0, cms = 0;
+            (void) hipEventElapsedTime(&ms, ev[0], ev[1]);
+            (void) hipEventElapsedTime(&cms, ev[2], ev[3]);
+            stats->kernel_ms = ms;
+            stats->d2h_ms = cms;
+            stats->edges_reached = (int64_t) edges_reached;
+        }
+    }
+    for (hipEvent_t e : ev)
+        if (e) (void) hipEventDestroy(e);
+    gmx_bfs_free(b);
+    return st;
 }
