@@ -104,7 +104,8 @@ class DistPageRank:
     barrier: how ranks are ordered after a pushed step -- "collective" (all-reduce of diff on the device, the
     production path) or "host" (stream sync + host barrier; for ranks sharing one GPU, where RCCL cannot run)."""
 
-    def __init__(self, engine, group=None, always_exchange=False, exchange="collective", barrier="collective"):
+    def __init__(self, engine, group=None, always_exchange=False, exchange="collective", barrier="collective",
+                 verify_push=True):
         self.engine = engine
         self.group = group
         self.initialized = dist.is_available() and dist.is_initialized()
@@ -113,6 +114,8 @@ class DistPageRank:
         self.always_exchange = always_exchange and self.initialized
         self.cnt = 0
         self.barrier = barrier
+        self.verify_push = verify_push    # check the first pushed exchange against a collective one
+        self.push_verified = False
         self._diff = None
         self.exchange = "collective"
         if exchange in ("push", "auto") and self.world > 1:
@@ -142,6 +145,19 @@ class DistPageRank:
             raise RuntimeError("peer push unavailable on rank(s) %s: %s" % ([r for r, f in enumerate(flags) if not f], err))
         return False
 
+    def _push_matches_collective(self):
+        full = self.engine.contrib_full()
+        mine = self.engine.contrib_slice()
+        n = mine.numel()
+        need = self.engine.exchange_count() if hasattr(self.engine, "exchange_count") else n
+        if self.barrier == "host":          # ranks sharing one GPU: the host barrier already ordered the copies
+            got = [torch.empty_like(mine[:need]).cpu() for _ in range(self.world)]
+            dist.all_gather(got, mine[:need].cpu(), group=self.group)
+            return all(torch.equal(got[r], full[r * n:r * n + need].cpu()) for r in range(self.world))
+        got = [torch.empty_like(mine[:need]) for _ in range(self.world)]
+        dist.all_gather(got, mine[:need].clone(), group=self.group)
+        return all(bool(torch.equal(got[r], full[r * n:r * n + need])) for r in range(self.world))
+
     def _rank_barrier(self):
         """After a pushed step: nobody goes on before every rank's copies have completed.  Carries diff."""
         t = self.engine.diff_tensor().clone()
@@ -167,9 +183,25 @@ class DistPageRank:
         if self.world == 1 and not self.always_exchange:
             return
         if self.exchange == "push":
-            self.engine.push_current()
-            self.engine.push_join()
+            ok = 1
+            try:
+                self.engine.push_current()
+                self.engine.push_join()
+            except Exception:   # noqa: BLE001 -- a refused peer copy: every rank falls back together below
+                if not (self.verify_push and not self.push_verified):
+                    raise
+                ok = 0
             self._rank_barrier()
+            if self.verify_push and not self.push_verified:
+                # once, outside any timed region: what the peers pushed into this replica must be what a
+                # collective all-gather of the same slices delivers; otherwise every rank falls back to it
+                self.push_verified = True
+                ok = ok and self._push_matches_collective()
+                flags = [None] * self.world
+                dist.all_gather_object(flags, int(ok), group=self.group)
+                if not all(flags):
+                    self.exchange = "collective"
+                    self._exchange()
             return
         full = self.engine.contrib_full()
         mine = self.engine.contrib_slice()

@@ -137,6 +137,13 @@ class SharedFileEngine(NumpyEngine):
         pass
 
 
+class BrokenPushEngine(SharedFileEngine):
+    """Peer copies that silently land nowhere: DistPageRank's one-time check must notice and fall back."""
+
+    def _push(self, b, off, cnt):
+        pass
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -145,7 +152,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, scale, out_dir, chunks=1, push=False):
+def _worker(rank, world, port, scale, out_dir, chunks=1, push=False, broken=False):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (os.path.join(here, "..", "green-marl_amd"), os.path.join(here, "..", "oracle")):
@@ -155,26 +162,29 @@ def _worker(rank, world, port, scale, out_dir, chunks=1, push=False):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = po.rmat_graph(scale, permute=True)
-    eng = SharedFileEngine(g, rank, world, out_dir) if push else NumpyEngine(g, rank, world)
+    eng = (BrokenPushEngine if broken else SharedFileEngine)(g, rank, world, out_dir) if push else NumpyEngine(g, rank, world)
     eng.set_chunks(chunks)
     pr = DistPageRank(eng, exchange="push", barrier="host") if push else DistPageRank(eng)
     assert pr.exchange == ("push" if push else "collective")
     cnt, diff = pr.run(0.001, 0.85, 100)
+    assert pr.exchange == ("push" if push and not broken else "collective")   # broken copies: fell back
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), eng.rank_v)
     np.save(os.path.join(out_dir, "meta%d.npy" % rank), np.array([cnt, diff, eng.lo, eng.hi]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,chunks,push", [(2, 1, False), (3, 1, False), (2, 4, False), (3, 3, False),
-                                                (2, 1, True), (3, 2, True)])
-def test_dist_pagerank_gloo(tmp_path, world, chunks, push):
+@pytest.mark.parametrize("world,chunks,push,broken", [(2, 1, False, False), (3, 1, False, False), (2, 4, False, False),
+                                                       (3, 3, False, False), (2, 1, True, False), (3, 2, True, False),
+                                                       (2, 2, True, True)])
+def test_dist_pagerank_gloo(tmp_path, world, chunks, push, broken):
     """chunks > 1: the sweep is enqueued in row chunks and each chunk's piece is all-gathered (async) while
     the next chunk is computed -- the overlap path the GPU ranks take for N > 1.
     push: the exchange by direct copies into the peers' replicas (files here, hipIpc-mapped HBM on the GPUs),
-    ordered by the per-step all-reduce of diff."""
+    ordered by the per-step all-reduce of diff.  broken: the copies do nothing -- the first exchange is checked
+    against a collective one and every rank falls back to the all-gather."""
     scale = 11
-    mp.spawn(_worker, args=(world, _free_port(), scale, str(tmp_path), chunks, push), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), scale, str(tmp_path), chunks, push, broken), nprocs=world, join=True)
     g = po.rmat_graph(scale, permute=True)
     want, it, want_diff = po.pagerank(g, 0.001, 0.85, 100, nthreads=1)
     got = np.zeros(g.N)

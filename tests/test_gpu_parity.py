@@ -237,7 +237,7 @@ def test_pagerank_partitioned_ranks_in_one_process(gmx, nranks, options):
 
 
 @pytest.mark.parametrize("scale,nranks,chunks,elem", [(15, 2, 4, 8), (15, 4, 3, 8), (15, 1, 8, 8), (18, 2, 8, 8), (18, 8, 4, 4),
-                                                       (12, 2, 4, 8)])
+                                                       (12, 2, 4, 8), (15, 3, 2, 8), (16, 5, 3, 4)])
 def test_pagerank_row_chunked_steps(gmx, scale, nranks, chunks, elem):
     """gmx_pr_step_chunk: a sweep enqueued as C row chunks, each chunk's piece exchanged (device copies
     standing in for the all-gather) before the next chunk is computed -- the order of events of the
