@@ -930,6 +930,8 @@ pr_combine_kernel(pr_sliced_args a, const int32_t* __restrict__ active, int64_t 
         __builtin_nontemporal_store(od > 0 ? (S) ((double) vs / (double) od) : (S) 0, contrib_next_owned + r);
     }
     pr_block_diff<256>(diff_acc, s_red, diff_part + blockIdx.x);
+    // the sweep of this chunk is over: leave the work queues at zero for the next launch (saves a memset)
+    if (blockIdx.x == 0 && threadIdx.x < PR_MAX_SLICES) a.queue[threadIdx.x * PR_QUEUE_STRIDE] = 0;
 }
 
 // Plan: position of every active row in active[]; the slices' compact rows are renamed to it.
@@ -1029,10 +1031,11 @@ __global__ void pr_mark_active_kernel(const uint64_t* __restrict__ keys, int64_t
         if (i == 0 || (keys[i - 1] >> 32) != (keys[i] >> 32)) is_active[(int64_t) (keys[i] >> 32) - row_lo] = 1;
 }
 
-__global__ void pr_diff_reduce_kernel(const double* __restrict__ part, int64_t n, double* __restrict__ out) {
+// sums `take` entries of each of `groups` groups laid out `stride` apart (fixed order: deterministic)
+__global__ void pr_diff_reduce_kernel(const double* __restrict__ part, int64_t groups, int64_t stride, int64_t take, double* __restrict__ out) {
     __shared__ double s[1024 / 64];
     double t = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) t += part[i];
+    for (int64_t i = threadIdx.x; i < groups * take; i += blockDim.x) t += part[(i / take) * stride + i % take];
     t = wave_sum(t);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = t;
     __syncthreads();
@@ -1293,7 +1296,8 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 const size_t partial_bytes = (size_t) ns * nact_alloc * elem_bytes;
                 if ((st = p->sl_blk.alloc(npart)) || (st = p->sl_part_first.alloc(npart)) || (st = p->sl_part_last.alloc(npart)) ||
                     (st = p->sl_partial.alloc(partial_bytes)) || (st = p->sl_queue.alloc(PR_MAX_SLICES * PR_QUEUE_STRIDE))) break;
-                if (hipMemset(p->sl_partial.p, 0, partial_bytes) != hipSuccess) { gmx_set_error("pr plan: memset failed"); st = GMX_ERR_HIP; break; }
+                if (hipMemset(p->sl_partial.p, 0, partial_bytes) != hipSuccess ||
+                    hipMemset(p->sl_queue.p, 0, sizeof(unsigned int) * PR_MAX_SLICES * PR_QUEUE_STRIDE) != hipSuccess) { gmx_set_error("pr plan: memset failed"); st = GMX_ERR_HIP; break; }
                 memset(&p->sl, 0, sizeof(p->sl));
                 p->sl.ns = ns;
                 p->sl.queue = p->sl_queue.p;
@@ -1402,7 +1406,7 @@ static void launch_wave(gmx_pr* p, hipStream_t s) {
     hipLaunchKernelGGL(pr_fixup_kernel<S>, dim3((unsigned) fix_blocks), dim3(256), 0, s,
                        p->blk.p, p->nblk, p->rows, p->rb, p->outdeg.p, (S*) p->rk.p, next_owned, base, p->d,
                        p->part_first.p, p->part_last.p, (const double*) p->diff_part.p, n_main, diff_fix);
-    hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) diff_fix, fix_blocks, p->diff.p);
+    hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) diff_fix, (int64_t) 1, (int64_t) fix_blocks, (int64_t) fix_blocks, p->diff.p);
 }
 
 // Row-chunk boundaries over the exchanged prefix [0, exchange_count) of a rank's range, the same on every rank.
@@ -1461,7 +1465,6 @@ static void launch_sliced_chunk(gmx_pr* p, int c, hipStream_t s) {
     const int C = p->nchunks;
     const int j = C - 1 - c;
     S* next_owned = (S*) p->contrib[1 - p->cur].p + p->row_lo;
-    (void) hipMemsetAsync(p->sl_queue.p, 0, sizeof(unsigned int) * PR_MAX_SLICES * PR_QUEUE_STRIDE, s);
     pr_sliced_args a = p->sl;
     int64_t maxfix = 0, total_blk = 0;
     for (int q = 0; q < p->ns; q++) {
@@ -1527,10 +1530,10 @@ static void launch_sliced_chunk(gmx_pr* p, int c, hipStream_t s) {
         if (c == C - 1)
             hipLaunchKernelGGL(pr_inactive_copy_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, (const uint8_t*) p->sl_is_active.p,
                                p->rows, (S*) p->contrib[p->cur].p + p->row_lo, (const S*) next_owned);
-    } else (void) hipMemsetAsync(dpart + PR_COMBINE_GRID, 0, sizeof(double) * PR_COMBINE_GRID, s);
-    if (c == C - 1)
-        hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) p->diff_part.p,
-                           (int64_t) C * 2 * PR_COMBINE_GRID, p->diff.p);
+    }
+    if (c == C - 1)   // per chunk: the combine partials, and in the first sweep those of the rows without in-edges
+        hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) p->diff_part.p, (int64_t) C,
+                           (int64_t) 2 * PR_COMBINE_GRID, (int64_t) (p->cnt == 0 ? 2 : 1) * PR_COMBINE_GRID, p->diff.p);
 }
 
 extern "C" int gmx_pr_set_chunks(gmx_pr_t* p, int chunks) {
