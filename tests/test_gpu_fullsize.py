@@ -133,13 +133,21 @@ def test_triangle_counting_two_algorithms(gmx, scale):
     gs.free()
 
 
-def test_triangle_counting_rmat24_symmetrized_runs(gmx):
-    """BASELINE configs[4]: triangle counting on RMAT-24 (symmetrised + de-duplicated on the device)."""
+def test_triangle_counting_rmat24_symmetrized_runs(gmx, monkeypatch):
+    """BASELINE configs[4]: triangle counting on RMAT-24 (symmetrised + de-duplicated on the device).  The
+    count on the degree-ordered copy must equal the count in the emitted vertex order on the same graph."""
     g = gmx.Graph.rmat(1 << 24, 16 << 24, 1997, 0.57, 0.19, 0.19, False)
     gs = g.symmetrize()
     g.free()
     T, st = gs.triangle_counting()
-    assert T > 0 and st["kernel_ms"] > 0
+    T2, st2 = gs.triangle_counting()          # second call: the degree-ordered copy is cached on the graph
+    assert T > 0 and st["kernel_ms"] > 0 and T2 == T
+    monkeypatch.setenv("GMX_TC_NO_ORIENT", "1")
+    T_emitted, st_e = gs.triangle_counting()
+    monkeypatch.delenv("GMX_TC_NO_ORIENT")
+    assert T == T_emitted
+    print("emitted order: %.1f ms; degree order: %.1f ms (first call, copy built outside the timed region), %.1f ms (cached)"
+          % (st_e["kernel_ms"], st["kernel_ms"], st2["kernel_ms"]))
     # a triangle {a<b<c} of a simple undirected graph is counted exactly once by the emitted rule, so
     # T is bounded by sum_v C(d(v),2)/... ; sanity: T <= E * max_degree
     b = gs.download(reverse=False)[0]

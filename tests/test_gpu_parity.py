@@ -389,6 +389,35 @@ def test_triangle_counting_parts_add_up(gmx, nparts):
     g.free()
 
 
+def test_triangle_counting_degree_oriented_path(gmx, monkeypatch):
+    """Symmetric simple graphs are counted on a degree-ordered copy (T is numbering-independent there); the
+    count must equal the emitted-order count and the oracle's.  Symmetric graphs WITH duplicate slots or
+    self-loops, and directed graphs, must keep the emitted order (multiplicity rule)."""
+    for scale in (10, 14, 16):
+        sym = po.symmetrize(po.rmat_graph(scale, permute=True))
+        g = gmx.Graph.upload(sym.begin, sym.node_idx, sym.r_begin, sym.r_node_idx)
+        fast = g.triangle_counting()[0]
+        parts = sum(g.triangle_counting(p, 3)[0] for p in range(3))
+        g.free()
+        monkeypatch.setenv("GMX_TC_NO_ORIENT", "1")
+        g = gmx.Graph.upload(sym.begin, sym.node_idx, sym.r_begin, sym.r_node_idx)
+        plain = g.triangle_counting()[0]
+        g.free()
+        monkeypatch.delenv("GMX_TC_NO_ORIENT")
+        assert fast == plain == parts == po.triangle_counting(sym)
+    # symmetric but not simple: every edge twice, plus self-loops
+    rng = np.random.default_rng(11)
+    V = 300
+    a = rng.integers(0, V, 4000).astype(np.int32)
+    b = rng.integers(0, V, 4000).astype(np.int32)
+    src = np.concatenate([a, b, a, b, np.arange(20, dtype=np.int32)])
+    dst = np.concatenate([b, a, b, a, np.arange(20, dtype=np.int32)])
+    og = po.graph_from_edges(V, src, dst)
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    assert g.triangle_counting()[0] == po.triangle_counting(og)
+    g.free()
+
+
 def test_dist_engine_world1_and_kernel_timing(gmx):
     from dist_pagerank import DistPageRank, GmxEngine
     og = po.rmat_graph(14, permute=True)
