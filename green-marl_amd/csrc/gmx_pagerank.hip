@@ -1765,12 +1765,15 @@ extern "C" int gmx_pr_download(gmx_pr_t* p, void* rank_host) {
     return GMX_OK;
 }
 
-// Variant choice by size (measured on RMAT, edge factor 16): up to 2^21 vertices the contribution
-// vector (8 MiB fp32) lives in L2 and the unsliced kernel with an LDS hot tile wins; from 2^22 on,
-// splitting the sources over the XCD L2s pays for its partial-sum pass (RMAT-24: 1.21 vs 1.53 ms).
+// Variant choice by size (measured on RMAT, edge factor 16, fp32; ms per iteration plain / LDS tile / sliced):
+// 2^16: 0.018 / 0.028 / 0.056   2^18: 0.033 / 0.041 / 0.084   2^19: 0.058 / 0.055 / 0.090
+// 2^20: 0.097 / 0.085 / 0.115   2^21: 0.196 / 0.156 / 0.152    2^22 and up: sliced (RMAT-24: 1.01 vs 1.53 ms).
+// Up to 2^18 vertices the whole contribution vector sits in every L2 and filling an LDS tile per launch costs
+// more than it saves; up to 2^21 the unsliced kernel with the tile wins; beyond, splitting the sources over
+// the XCD L2s pays for its partial-sum pass.
 extern "C" uint32_t gmx_pr_default_options(int64_t V, int nranks) {
     uint32_t o = GMX_PR_RELABEL;
-    o |= GMX_PR_HOT_LDS;   // with several ranks the tile is only used by the sliced kernel
+    if (V > (1LL << 18)) o |= GMX_PR_HOT_LDS;   // with several ranks the tile is only used by the sliced kernel
     if (V > (1LL << 21)) o |= GMX_PR_SLICED;
     return o;
 }
