@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--exchange", default="auto", choices=["auto", "push", "collective"],
                     help="N > 1: peer copies over xGMI (hipIpc + copy engines) or RCCL all-gather; auto = push if it sets up")
     ap.add_argument("--cpu-scale", type=int, default=24)
-    ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--cpu-iters", type=int, default=30)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
