@@ -575,3 +575,36 @@ extern "C" int gmx_graph_download(const gmx_graph_t* g, gmx_edge_t* begin, gmx_n
     if (r_node_idx && g->E) GMX_HIP(hipMemcpy(r_node_idx, g->r_node_idx.p, sizeof(int32_t) * (size_t) g->E, hipMemcpyDeviceToHost));
     return GMX_OK;
 }
+
+// e_rev2idx of gm_graph (/root/reference/apps/output_cpp/gm_graph/inc/gm_graph.h:141-142; built by
+// make_reverse_edges, gm_graph.cc:205-304): for every slot of the reverse CSR the forward slot it mirrors.
+// The reverse CSR is the forward edge list sorted by (dst, src); sorting the forward slot numbers along
+// (stable radix sort of (dst << 32 | src) keys with the slot as value) gives the map directly, the k-th copy
+// of a repeated edge in an in-row mirroring the k-th slot holding it in the out-row.
+__global__ void iota_kernel(int32_t* __restrict__ a, int64_t n) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) a[i] = (int32_t) i;
+}
+
+extern "C" int gmx_graph_reverse_edge_map(const gmx_graph_t* g, gmx_edge_t* e_rev2idx) {
+    GMX_REQUIRE(g && e_rev2idx, "NULL argument");
+    if (g->E == 0) return GMX_OK;
+    hipStream_t s = 0;
+    dbuf<uint64_t> keys, keys2;
+    dbuf<int32_t> val, val2;
+    GMX_CHECK(keys.alloc((size_t) g->E));
+    GMX_CHECK(keys2.alloc((size_t) g->E));
+    GMX_CHECK(val.alloc((size_t) g->E));
+    GMX_CHECK(val2.alloc((size_t) g->E));
+    GMX_CHECK(gmx_keys_from_csr(g->begin.p, g->node_idx.p, g->V, g->E, true, nullptr, keys.p, s));
+    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(g->E)), dim3(256), 0, s, val.p, g->E);
+    size_t tb = 0;
+    const unsigned end_bit = 32 + (unsigned) gmx_bits_for(g->V);
+    GMX_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys2.p, val.p, val2.p, (size_t) g->E, 0u, end_bit, s));
+    dbuf<char> tmp;
+    GMX_CHECK(tmp.alloc(tb));
+    GMX_HIP(rocprim::radix_sort_pairs((void*) tmp.p, tb, keys.p, keys2.p, val.p, val2.p, (size_t) g->E, 0u, end_bit, s));
+    GMX_HIP(hipMemcpy(e_rev2idx, val2.p, sizeof(int32_t) * (size_t) g->E, hipMemcpyDeviceToHost));
+    return GMX_OK;
+}

@@ -9,8 +9,24 @@
 #include <string.h>
 #include <algorithm>
 
+#include <stdlib.h>
+#include <sys/time.h>
+
 #include "gm_graph.h"
 #include "gmx.h"
+
+// GMX_LOAD_TIMING=1: where load_binary spends its time (stderr)
+static double load_now_ms() {
+    struct timeval tv;
+    gettimeofday(&tv, NULL);
+    return tv.tv_sec * 1e3 + tv.tv_usec * 1e-3;
+}
+static void load_mark(const char* what, double& t) {
+    if (!getenv("GMX_LOAD_TIMING")) return;
+    const double n = load_now_ms();
+    fprintf(stderr, "load_binary: %-28s %8.1f ms\n", what, n - t);
+    t = n;
+}
 
 static bool read_u32_array(FILE* f, int32_t* dst, size_t n, bool swap) {
     if (n && fread(dst, 4, n, f) != n) return false;
@@ -28,6 +44,7 @@ bool gm_graph::load_binary(char* filename) {
         fprintf(stderr, "cannot open %s for reading\n", filename);
         return false;
     }
+    double tmark = load_now_ms();
     uint32_t hdr[3];
     bool ok = fread(hdr, 4, 3, f) == 3;
     bool swap = true;
@@ -67,11 +84,13 @@ bool gm_graph::load_binary(char* filename) {
         clear_graph();
         return false;
     }
+    load_mark("read + byte swap", tmark);
     // Post-load preparation (the reference: per-row std::sort + atomic scatter, both on the host,
     // gm_graph_binary_loader.cc:191-197).  Rows are sorted on the host (parallel, rows already in order are
     // skipped); with a GPU present the reverse CSR is built on the device (transposed 64-bit key radix sort,
     // SURVEY.md section 8f rank 1) and copied back, the device copy staying as the mirror the kernels use.
     do_semi_sort();
+    load_mark("do_semi_sort (host)", tmark);
     int ndev = 0;
     if (_numEdges > 0 && gmx_device_count(&ndev) == GMX_OK && ndev > 0 && build_reverse_on_device()) return true;
     make_reverse_edges();
@@ -80,15 +99,18 @@ bool gm_graph::load_binary(char* filename) {
 
 bool gm_graph::build_reverse_on_device() {
     gmx_graph_t* dev = NULL;
+    double tmark = load_now_ms();
     if (gmx_graph_upload(begin, node_idx, NULL, NULL, _numNodes, _numEdges, 0, &dev) != GMX_OK) {
         fprintf(stderr, "load_binary: device preparation failed (%s), using the host path\n", gmx_last_error());
         return false;
     }
+    load_mark("upload + device reverse CSR", tmark);
     const node_t N = _numNodes;
     const edge_t M = _numEdges;
     r_begin = new edge_t[(size_t) N + 1];
     r_node_idx = new node_t[(size_t) M];
     e_rev2idx = new edge_t[(size_t) M];
+    load_mark("host allocations", tmark);
     if (gmx_graph_download(dev, NULL, NULL, r_begin, r_node_idx) != GMX_OK) {
         fprintf(stderr, "load_binary: download failed (%s), using the host path\n", gmx_last_error());
         gmx_graph_free(dev);
@@ -97,18 +119,18 @@ bool gm_graph::build_reverse_on_device() {
         delete[] e_rev2idx; e_rev2idx = NULL;
         return false;
     }
-    // reverse slot -> forward slot: the k-th copy of (w -> t) in the in-row of t is the k-th slot holding t in row w
-#pragma omp parallel for schedule(dynamic, 4096)
-    for (node_t t = 0; t < N; t++) {
-        for (edge_t e = r_begin[t]; e < r_begin[t + 1]; e++) {
-            const node_t w = r_node_idx[e];
-            edge_t k = 0;
-            while (e - k - 1 >= r_begin[t] && r_node_idx[e - k - 1] == w) k++;
-            const node_t* lo = node_idx + begin[w];
-            const node_t* hi = node_idx + begin[w + 1];
-            e_rev2idx[e] = (edge_t) (std::lower_bound(lo, hi, t) - node_idx) + k;
-        }
+    load_mark("download reverse CSR", tmark);
+    // reverse slot -> forward slot (the k-th copy of (w -> t) in the in-row of t mirrors the k-th slot holding t
+    // in row w): the device sorts the forward slot numbers along with the (dst, src) keys
+    if (gmx_graph_reverse_edge_map(dev, e_rev2idx) != GMX_OK) {
+        fprintf(stderr, "load_binary: edge map failed (%s), using the host path\n", gmx_last_error());
+        gmx_graph_free(dev);
+        delete[] r_begin; r_begin = NULL;
+        delete[] r_node_idx; r_node_idx = NULL;
+        delete[] e_rev2idx; e_rev2idx = NULL;
+        return false;
     }
+    load_mark("e_rev2idx (device) + download", tmark);
     _reverse_edge = true;
     drop_device_mirror();
     _dev = dev;

@@ -91,6 +91,8 @@ int gmx_graph_symmetrize(const gmx_graph_t* g, gmx_graph_t** out);
 int gmx_graph_free(gmx_graph_t* g);
 int64_t gmx_graph_num_nodes(const gmx_graph_t* g);
 int64_t gmx_graph_num_edges(const gmx_graph_t* g);
+/* gm_graph's e_rev2idx[E] (gm_graph.h:141-142): forward slot mirrored by each slot of the reverse CSR. */
+int gmx_graph_reverse_edge_map(const gmx_graph_t* g, gmx_edge_t* e_rev2idx);
 /* Copy the device CSR back (any pointer may be NULL).  Lets a host gm_graph be
  * filled from a device-generated graph. */
 int gmx_graph_download(const gmx_graph_t* g, gmx_edge_t* begin, gmx_node_t* node_idx,

@@ -2,6 +2,7 @@
 // Python test to compare with the reference-generated fixtures.
 //   gm_graph_check <in.bin> <out.bin> <dump.txt>
 #include <stdio.h>
+#include <vector>
 #include <stdlib.h>
 #include "gm.h"
 
@@ -22,10 +23,14 @@ int main(int argc, char** argv) {
     dump(f, "node_idx", G.node_idx, G.num_edges());
     dump(f, "r_begin", G.r_begin, G.num_nodes() + 1);
     dump(f, "r_node_idx", G.r_node_idx, G.num_edges());
-    // e_rev2idx maps every reverse edge to a forward edge with swapped endpoints
+    // e_rev2idx maps every reverse edge to a forward edge with swapped endpoints, one to one (copies of a
+    // repeated edge in order)
+    std::vector<char> seen((size_t) G.num_edges(), 0);
     for (node_t v = 0; v < G.num_nodes(); v++)
         for (edge_t e = G.r_begin[v]; e < G.r_begin[v + 1]; e++) {
             edge_t fe = G.e_rev2idx[e];
+            if (fe < 0 || fe >= G.num_edges() || seen[fe]++) return 8;
+            if (e > G.r_begin[v] && G.r_node_idx[e - 1] == G.r_node_idx[e] && G.e_rev2idx[e - 1] >= fe) return 9;
             if (G.node_idx[fe] != v) return 4;
             node_t src = G.r_node_idx[e];
             if (!(G.begin[src] <= fe && fe < G.begin[src + 1])) return 5;

@@ -418,6 +418,23 @@ def test_triangle_counting_degree_oriented_path(gmx, monkeypatch):
     g.free()
 
 
+def test_reverse_edge_map(gmx, golden):
+    """gmx_graph_reverse_edge_map = gm_graph's e_rev2idx: a one-to-one map from reverse slots to forward slots
+    with swapped endpoints, copies of a repeated edge in order (what make_reverse_edges leaves after the sort)."""
+    for og in (po.rmat_graph(12, permute=False), po.rmat_graph(10, permute=True)):   # RMAT keeps multi-edges
+        g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+        m = g.reverse_edge_map()
+        g.free()
+        E = og.M
+        assert np.array_equal(np.sort(m), np.arange(E))
+        rdst = np.repeat(np.arange(og.N), np.diff(og.r_begin))          # destination of every reverse slot
+        fsrc = np.repeat(np.arange(og.N), np.diff(og.begin))            # source of every forward slot
+        assert np.array_equal(og.node_idx[m], rdst)
+        assert np.array_equal(fsrc[m], og.r_node_idx)
+        same = (rdst[1:] == rdst[:-1]) & (og.r_node_idx[1:] == og.r_node_idx[:-1])
+        assert np.all(m[1:][same] > m[:-1][same])
+
+
 def test_dist_engine_world1_and_kernel_timing(gmx):
     from dist_pagerank import DistPageRank, GmxEngine
     og = po.rmat_graph(14, permute=True)
