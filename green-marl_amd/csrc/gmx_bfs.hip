@@ -446,3 +446,160 @@ extern "C" int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host,
     gmx_bfs_free(b);
     return st;
 }
+
+// ------------------------------------------------------------------ sssp
+// The emitted `sssp` (/root/reference/apps/src/sssp.gm:1-30) is hop_dist's loop with an edge property:
+//     <s.dist_nxt; s.updated_nxt> min= <n.dist + e.len; True>     e = the out-edge slot being walked
+// until nothing changes.  dist[v] is the length of a shortest path over out-edges (INT_MAX: unreachable) --
+// unique, so the device is free to relax asynchronously: the updated vertices form a queue, their out-edges
+// are cut by merge-path exactly as in the top-down BFS level, every edge does atomicMin(dist[s], dist[n] +
+// len[e]) in place, and a vertex whose distance dropped enters the next queue once per round (round stamp).
+// Integer only: bit-exact against the CPU result.
+__global__ void __launch_bounds__(BFS_THREADS)
+sssp_relax_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx, const int32_t* __restrict__ len,
+                  const int32_t* __restrict__ cur_q, int64_t n, const int64_t* __restrict__ off, int64_t m,
+                  int32_t round, int32_t* __restrict__ dist, int32_t* __restrict__ stamp, int32_t* __restrict__ next_q,
+                  bfs_counters* __restrict__ ctr) {
+    __shared__ int64_t s_off[BFS_ITEMS + 2];
+    __shared__ int32_t s_row[BFS_ITEMS + 2];
+    __shared__ int32_t s_dist[BFS_ITEMS + 2];
+    __shared__ int64_t s_split[2][2];
+    const int tid = threadIdx.x;
+    if (tid < 2) {
+        int64_t dk = ((int64_t) blockIdx.x + tid) * BFS_ITEMS;
+        if (dk > n + m) dk = n + m;
+        int64_t lo = dk > m ? dk - m : 0, hi = dk < n ? dk : n;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (off[mid + 1] <= dk - mid - 1) lo = mid + 1; else hi = mid;
+        }
+        s_split[tid][0] = lo;
+        s_split[tid][1] = dk - lo;
+    }
+    __syncthreads();
+    const int64_t v0 = s_split[0][0], e0 = s_split[0][1], v1 = s_split[1][0], e1 = s_split[1][1];
+    const int nv = (int) (v1 - v0) + 1;
+    for (int i = tid; i < nv; i += BFS_THREADS) {
+        const int64_t vi = v0 + i;
+        s_off[i] = vi <= n ? off[vi < n ? vi : n] : m;
+        const int32_t v = vi < n ? cur_q[vi] : 0;
+        s_row[i] = vi < n ? begin[v] : 0;
+        s_dist[i] = vi < n ? dist[v] : 0;      // may already be lower than when v was queued: even better
+    }
+    if (tid == 0) s_off[nv] = m + 1;
+    __syncthreads();
+    unsigned long long inspected = 0;
+    for (int64_t x = e0 + tid; x < e1; x += BFS_THREADS) {
+        int lo = 0, hi = nv - 1;
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (s_off[mid] <= x) lo = mid; else hi = mid - 1;
+        }
+        const int64_t e = (int64_t) s_row[lo] + (x - s_off[lo]);
+        const int32_t s = node_idx[e];
+        const int32_t nd = s_dist[lo] + len[e];
+        inspected++;
+        bool won = false;
+        if (nd < dist[s] && nd < atomicMin(&dist[s], nd)) won = atomicExch(&stamp[s], round) != round;
+        const unsigned long long mk = __ballot(won);
+        if (mk) {
+            const int lane = threadIdx.x & 63;
+            const int leader = __ffsll((long long) mk) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(&ctr->next_count, (unsigned long long) __popcll(mk));
+            base = __shfl(base, leader, 64);
+            if (won) next_q[base + __popcll(mk & ((1ULL << lane) - 1))] = s;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) inspected += __shfl_down(inspected, o, 64);
+    if ((tid & 63) == 0 && inspected) atomicAdd(&ctr->edges, inspected);
+}
+
+__global__ void sssp_init_kernel(int32_t* __restrict__ dist, int32_t* __restrict__ stamp, int64_t V, int32_t root) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < V; i += stride) {
+        dist[i] = (i == root) ? 0 : INT_MAX;
+        stamp[i] = -1;
+    }
+}
+
+extern "C" int gmx_sssp(gmx_graph_t* g, gmx_node_t root, const int32_t* len_host, int32_t* dist_host, gmx_stats_t* stats) {
+    GMX_REQUIRE(g && dist_host, "NULL argument");
+    GMX_REQUIRE(len_host || g->E == 0, "len is NULL");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    const int64_t V = g->V;
+    if (V == 0) return GMX_OK;
+    const bool root_ok = root >= 0 && root < V;
+    dbuf<int32_t> dist, stamp, q0, q1, deg, len;
+    dbuf<int64_t> off;
+    dbuf<bfs_counters> ctr;
+    dbuf<char> scan_tmp;
+    size_t scan_bytes = 0;
+    GMX_CHECK(dist.alloc((size_t) V));
+    GMX_CHECK(stamp.alloc((size_t) V));
+    GMX_CHECK(q0.alloc((size_t) V));
+    GMX_CHECK(q1.alloc((size_t) V));
+    GMX_CHECK(deg.alloc((size_t) V));
+    GMX_CHECK(off.alloc((size_t) V + 2));
+    GMX_CHECK(ctr.alloc(1));
+    GMX_CHECK(len.alloc((size_t) (g->E ? g->E : 1)));
+    GMX_HIP(rocprim::inclusive_scan(nullptr, scan_bytes, deg.p, off.p + 1, (size_t) V, rocprim::plus<int64_t>(), 0));
+    GMX_CHECK(scan_tmp.alloc(scan_bytes));
+    hipEvent_t ev[4];
+    for (hipEvent_t& e : ev) GMX_HIP(hipEventCreate(&e));
+    GMX_HIP(hipEventRecord(ev[2], 0));
+    if (g->E) GMX_HIP(hipMemcpy(len.p, len_host, sizeof(int32_t) * (size_t) g->E, hipMemcpyHostToDevice));   // the property is the caller's
+    GMX_HIP(hipEventRecord(ev[3], 0));
+    GMX_HIP(hipEventRecord(ev[0], 0));
+    hipLaunchKernelGGL(sssp_init_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, dist.p, stamp.p, V, root_ok ? root : -1);
+    int64_t cur_count = 0, requeued = 0;
+    unsigned long long edges = 0;
+    int32_t round = 0;
+    int32_t* cur_q = q0.p;
+    int32_t* next_q = q1.p;
+    if (root_ok) {
+        GMX_HIP(hipMemcpy(q0.p, &root, sizeof(int32_t), hipMemcpyHostToDevice));
+        cur_count = 1;
+    }
+    while (cur_count > 0) {
+        bfs_counters zero = {0, edges};
+        GMX_HIP(hipMemcpy(ctr.p, &zero, sizeof(zero), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(bfs_degree_kernel, dim3(grid_for(cur_count)), dim3(BFS_THREADS), 0, 0, g->begin.p, cur_q, cur_count, deg.p);
+        size_t tb = scan_bytes;
+        GMX_HIP(rocprim::inclusive_scan(scan_tmp.p, tb, deg.p, off.p + 1, (size_t) cur_count, rocprim::plus<int64_t>(), 0));
+        GMX_HIP(hipMemsetAsync(off.p, 0, sizeof(int64_t), 0));
+        int64_t m_f = 0;
+        GMX_HIP(hipMemcpy(&m_f, off.p + cur_count, sizeof(int64_t), hipMemcpyDeviceToHost));
+        const int64_t nb = (cur_count + m_f + BFS_ITEMS - 1) / BFS_ITEMS;
+        if (nb > 0)
+            hipLaunchKernelGGL(sssp_relax_kernel, dim3((unsigned) nb), dim3(BFS_THREADS), 0, 0, g->begin.p, g->node_idx.p,
+                               (const int32_t*) len.p, cur_q, cur_count, off.p, m_f, round, dist.p, stamp.p, next_q, ctr.p);
+        GMX_HIP(hipGetLastError());
+        bfs_counters h;
+        GMX_HIP(hipMemcpy(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost));
+        cur_count = (int64_t) h.next_count;
+        edges = h.edges;
+        requeued += cur_count;
+        int32_t* t = cur_q;
+        cur_q = next_q;
+        next_q = t;
+        round++;
+    }
+    GMX_HIP(hipEventRecord(ev[1], 0));
+    GMX_HIP(hipEventSynchronize(ev[1]));
+    GMX_HIP(hipMemcpy(dist_host, dist.p, sizeof(int32_t) * (size_t) V, hipMemcpyDeviceToHost));
+    if (stats) {
+        float ms = 0, hms = 0;
+        (void) hipEventElapsedTime(&ms, ev[0], ev[1]);
+        (void) hipEventElapsedTime(&hms, ev[2], ev[3]);
+        stats->iterations = round;
+        stats->kernel_ms = ms;
+        stats->h2d_ms = hms;
+        stats->edges_examined = (int64_t) edges;
+        stats->vertices_reached = requeued + (root_ok ? 1 : 0);   // queue entries over all rounds (a vertex may re-enter)
+    }
+    for (hipEvent_t e : ev) (void) hipEventDestroy(e);
+    return GMX_OK;
+}

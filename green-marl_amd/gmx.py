@@ -43,7 +43,7 @@ EXPORTS = [
     "gmx_last_error", "gmx_device_count", "gmx_set_device", "gmx_device_info",
     "gmx_graph_upload", "gmx_graph_from_edges", "gmx_graph_create_rmat", "gmx_graph_free", "gmx_graph_symmetrize",
     "gmx_graph_num_nodes", "gmx_graph_num_edges", "gmx_graph_download",
-    "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_triangle_counting", "gmx_triangle_counting_part", "gmx_graph_reverse_edge_map",
+    "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_sssp", "gmx_triangle_counting", "gmx_triangle_counting_part", "gmx_graph_reverse_edge_map",
     "gmx_bfs_create", "gmx_bfs_free", "gmx_bfs_start", "gmx_bfs_step_begin", "gmx_bfs_found_bitmap", "gmx_bfs_step_end",
     "gmx_bfs_download",
     "gmx_pr_create", "gmx_pr_free", "gmx_pr_reset", "gmx_pr_step", "gmx_pr_contrib_slice",
@@ -92,6 +92,7 @@ def lib():
         L.gmx_pagerank_f32.argtypes = [vp, C.c_float, C.c_float, i32, vp, C.POINTER(Stats)]
         L.gmx_hop_dist.argtypes = [vp, i32, vp, C.POINTER(Stats)]
         L.gmx_triangle_counting.argtypes = [vp, C.POINTER(i64), C.POINTER(Stats)]
+        L.gmx_sssp.argtypes = [vp, i32, vp, vp, C.POINTER(Stats)]
         L.gmx_graph_reverse_edge_map.argtypes = [vp, vp]
         L.gmx_triangle_counting_part.argtypes = [vp, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(Stats)]
         L.gmx_bfs_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
@@ -261,6 +262,15 @@ class Graph:
         dist = np.empty(max(self.V, 1), np.int32)[: self.V].copy()
         st = Stats()
         _ck(lib().gmx_hop_dist(self._h, root, dist.ctypes.data, C.byref(st)))
+        return dist, st.as_dict()
+
+    def sssp(self, length, root=0):
+        """sssp(G, dist, len, root): length[E] int32 by forward edge slot -- returns (dist[int32], stats)."""
+        length = _i32(length)
+        assert len(length) == self.E
+        dist = np.zeros(max(self.V, 1), np.int32)[:self.V].copy()
+        st = Stats()
+        _ck(lib().gmx_sssp(self._h, int(root), length.ctypes.data if self.E else None, dist.ctypes.data, C.byref(st)))
         return dist, st.as_dict()
 
     def reverse_edge_map(self):

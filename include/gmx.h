@@ -140,6 +140,11 @@ int gmx_bfs_found_bitmap(gmx_bfs_t* b, void** words, int64_t* total_words, int64
 int gmx_bfs_step_end(gmx_bfs_t* b, int64_t* next_count);
 int gmx_bfs_download(gmx_bfs_t* b, int32_t* dist_host, gmx_stats_t* stats);
 
+/* sssp(G, dist, len, root) (apps/src/sssp.gm; driver apps/output_cpp/src/sssp_main.cc:42): shortest path lengths
+ * over out-edges with the caller's edge property len[E] (indexed by forward edge slot), INT_MAX = unreachable.
+ * stats: iterations = relaxation rounds, h2d_ms = upload of len, vertices_reached = queue entries over all rounds. */
+int gmx_sssp(gmx_graph_t* g, gmx_node_t root, const int32_t* len_host, int32_t* dist_host, gmx_stats_t* stats);
+
 /* triangle_counting(G) with the emitted multiplicity rule. */
 int gmx_triangle_counting(gmx_graph_t* g, int64_t* count, gmx_stats_t* stats);
 /* Multi-GPU form (replicated CSR, final all-reduce of int64): the count contributed by part

@@ -287,6 +287,79 @@ void gmo_pagerank(gmo_node_t numNodes,
 }
 
 /* ------------------------------------------------------------------ */
+/* sssp -- restated emission:                    */
+/*   source apps/src/sssp.gm:1-30 -- hop_dist's loop with an edge      */
+/*   property: `Edge e = s.ToEdge()` is the iterator of the out-       */
+/*   neighbour loop (src/backend_cpp/gm_cpp_gen_foreach.cc:161,286),   */
+/*   so e.len is G_len[s_idx]; everything else as gmo_hop_dist below.  */
+/*   Result: dist[v] = length of a shortest path root -> v over out-   */
+/*   edges, INT_MAX if unreachable (unique, schedule independent).     */
+/* ------------------------------------------------------------------ */
+void gmo_sssp(gmo_node_t numNodes,
+              const gmo_edge_t* begin, const gmo_node_t* node_idx, const int32_t* G_len,
+              gmo_node_t root, int32_t* G_dist, int nthreads, int32_t* rounds_out) {
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    size_t n = (size_t) (numNodes > 0 ? numNodes : 1);
+    uint8_t* G_updated = (uint8_t*) malloc(n);
+    uint8_t* G_updated_nxt = (uint8_t*) malloc(n);
+    int32_t* G_dist_nxt = (int32_t*) malloc(sizeof(int32_t) * n);
+    int fin = 0;
+    int32_t rounds = 0;
+
+#pragma omp parallel for num_threads(nthreads)
+    for (gmo_node_t t0 = 0; t0 < numNodes; t0++) {
+        G_dist[t0] = (t0 == root) ? 0 : INT_MAX;
+        G_updated[t0] = (t0 == root) ? 1 : 0;
+        G_dist_nxt[t0] = G_dist[t0];
+        G_updated_nxt[t0] = G_updated[t0];
+    }
+
+    while (!fin) {
+        int __E8 = 0;
+        fin = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 128)
+        for (gmo_node_t nn = 0; nn < numNodes; nn++) {
+            if (G_updated[nn]) {
+                for (gmo_edge_t s_idx = begin[nn]; s_idx < begin[nn + 1]; s_idx++) {
+                    gmo_node_t s = node_idx[s_idx];
+                    gmo_edge_t e = s_idx;
+                    int32_t nv = G_dist[nn] + G_len[e];
+                    int32_t cur = __atomic_load_n(&G_dist_nxt[s], __ATOMIC_RELAXED);
+                    while (cur > nv) {
+                        if (__atomic_compare_exchange_n(&G_dist_nxt[s], &cur, nv, 0,
+                                                        __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+                            G_updated_nxt[s] = 1;
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+#pragma omp parallel num_threads(nthreads)
+        {
+            int __E8_prv = 0;
+#pragma omp for nowait
+            for (gmo_node_t t4 = 0; t4 < numNodes; t4++) {
+                G_dist[t4] = G_dist_nxt[t4];
+                G_updated[t4] = G_updated_nxt[t4];
+                G_updated_nxt[t4] = 0;
+                __E8_prv = __E8_prv || G_updated[t4];
+            }
+            if (__E8_prv) {
+#pragma omp atomic write
+                __E8 = 1;
+            }
+        }
+        fin = !__E8;
+        rounds++;
+    }
+    if (rounds_out) *rounds_out = rounds;
+    free(G_updated);
+    free(G_updated_nxt);
+    free(G_dist_nxt);
+}
+
+/* ------------------------------------------------------------------ */
 /* hop_dist -- restated emission:                    */
 /*   source apps/src/hop_dist.gm:3-31                                  */
 /*   merged init loop (src/opt/gm_merge_loops.cc:228)                  */

@@ -85,6 +85,12 @@ void gmo_pagerank(gmo_node_t N,
                   double e, double d, int32_t max_iter, double* rank,
                   int nthreads, int32_t* iters_out, double* diff_out);
 
+/* ---- emitted kernel: sssp (apps/src/sssp.gm:1-30): hop_dist with the edge property
+ * len[E] (indexed by forward edge slot) in place of 1.  dist[v] = shortest path length, INT_MAX unreachable. */
+void gmo_sssp(gmo_node_t N,
+              const gmo_edge_t* begin, const gmo_node_t* node_idx, const int32_t* len,
+              gmo_node_t root, int32_t* dist, int nthreads, int32_t* rounds_out);
+
 /* ---- emitted kernel: hop_dist (apps/src/hop_dist.gm:3-31).
  * Level-synchronous push over OUT edges, INT_MAX = unreached. */
 void gmo_hop_dist(gmo_node_t N,

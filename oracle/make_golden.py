@@ -55,6 +55,7 @@ def ref_lib():
     R.ref_pagerank.argtypes = [C.c_int32, C.c_int32, i32p, i32p, C.c_double, C.c_double, C.c_int32, f64p,
                                C.c_int, C.POINTER(C.c_int32)]
     R.ref_hop_dist.argtypes = [C.c_int32, C.c_int32, i32p, i32p, C.c_int32, i32p, C.c_int]
+    R.ref_sssp.argtypes = [C.c_int32, C.c_int32, i32p, i32p, i32p, C.c_int32, i32p, C.c_int]
     R.ref_bfs_levels.argtypes = [C.c_int32, C.c_int32, i32p, i32p, C.c_int32, i32p, C.c_int, C.c_int]
     R.ref_triangle_counting.argtypes = [C.c_int32, C.c_int32, i32p, i32p, C.c_int]
     R.ref_triangle_counting.restype = C.c_int64
@@ -99,6 +100,35 @@ def ref_kernels(R, N, begin, node_idx, root=0, pr_args=(0.001, 0.85, 100), tc=Tr
     assert np.array_equal(dist, lv), "emitted hop_dist vs gm_bfs_template levels differ"
     T = int(R.ref_triangle_counting(N, M, begin, node_idx, 4)) if tc else None
     return rank, it.value, dist, T
+
+
+def sssp_lengths(M, salt):
+    """Edge lengths 1..100 as sssp_main.cc:33-34 draws them (there from gm_rand32; any positive lengths do)."""
+    return np.random.default_rng(1000003 * salt + M).integers(1, 101, M).astype(np.int32)
+
+
+def check_sssp(R, name, g, root, salt):
+    """sssp on the semi-sorted graph: oracle restatement == emission on the reference runtime == scipy Dijkstra."""
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph as csg
+    length = sssp_lengths(g.M, salt)
+    dist_r = e32(g.N)
+    R.ref_sssp(g.N, g.M, g.begin, g.node_idx, length, root, dist_r, 4)
+    dist_o, _ = po.sssp(g, length, root, nthreads=8)
+    assert np.array_equal(dist_o, dist_r), (name, "sssp")
+    dist_1, _ = po.sssp(g, length, root, nthreads=1)
+    assert np.array_equal(dist_1, dist_r), (name, "sssp 1 thread")
+    if g.M and 0 <= root < g.N:
+        src = np.repeat(np.arange(g.N), np.diff(g.begin))
+        order = np.lexsort((length, g.node_idx, src))            # cheapest copy of every parallel edge first
+        s, t, w = src[order], g.node_idx[order], length[order]
+        first = np.ones(len(s), bool)
+        first[1:] = (s[1:] != s[:-1]) | (t[1:] != t[:-1])
+        A = sp.csr_matrix((w[first].astype(np.float64), (s[first], t[first])), shape=(g.N, g.N))
+        dd = csg.dijkstra(A, indices=root)
+        want = np.where(np.isinf(dd), INT_MAX, dd).astype(np.int64)
+        assert np.array_equal(dist_r.astype(np.int64), want), (name, "sssp vs scipy")
+    return length, dist_r
 
 
 def check_oracle_on(R, name, N, begin, raw_or_sorted, pr_args=(0.001, 0.85, 100), root=0, tc=True):
@@ -161,6 +191,7 @@ def main():
         _, rank20, it20, _, _ = check_oracle_on(R, name + "_20it", N, begin, raw,
                                                 pr_args=(1e-300, 0.85, 20), root=root, tc=False)
         assert it20 == 20
+        sssp_len, sssp_dist = check_sssp(R, name, g, root, scale * 2 + perm)
         # symmetrised graph for the TC measurement config
         gs = po.symmetrize(g)
         Ts = None
@@ -191,11 +222,13 @@ def main():
                  "sha_begin": sha(begin), "sha_raw_node_idx": sha(raw), "sha_node_idx": sha(snode),
                  "sha_r_begin": sha(rb), "sha_r_node_idx": sha(rn), "sha_dist": sha(dist),
                  "sha_rank_f64": sha(rank), "sha_rank20_f64": sha(rank20),
+                 "sssp_salt": scale * 2 + perm, "sha_sssp_len": sha(sssp_len), "sha_sssp_dist": sha(sssp_dist),
+                 "sssp_reached": int((sssp_dist != INT_MAX).sum()), "sssp_max": int(sssp_dist[sssp_dist != INT_MAX].max()),
                  "rank_sum": float(rank.sum()), "rank_head": [float(x) for x in rank[:4]]}
         manifest["rmat"][name] = entry
         if scale <= 10:   # small enough to commit in full
             fixtures[name] = dict(begin=begin, raw_node_idx=raw, node_idx=snode, r_begin=rb, r_node_idx=rn,
-                                  rank=rank, rank20=rank20, dist=dist)
+                                  rank=rank, rank20=rank20, dist=dist, sssp_len=sssp_len, sssp_dist=sssp_dist)
         print("%s: pinned (iters=%d, reached=%d, T=%s, Tsym=%s)" % (name, it, entry["reached"], T, Ts))
 
     # ---- 3. hand graphs ----
@@ -217,8 +250,9 @@ def main():
         dst = np.array([e[1] for e in edges], np.int32)
         begin, raw = po.csr_from_edges(N, src, dst)
         g, rank, it, dist, T = check_oracle_on(R, name, N, begin, raw, root=root, tc=True)
+        sssp_len, sssp_dist = check_sssp(R, name, g, root, len(name))
         fixtures["hand_" + name] = dict(begin=begin, raw_node_idx=raw, node_idx=g.node_idx, r_begin=g.r_begin,
-                                        r_node_idx=g.r_node_idx, rank=rank, dist=dist)
+                                        r_node_idx=g.r_node_idx, rank=rank, dist=dist, sssp_len=sssp_len, sssp_dist=sssp_dist)
         manifest["hand"][name] = {"N": N, "M": len(edges), "root": root, "pr_iters": it, "tc": T}
         print("hand %s: pinned (iters=%d T=%d)" % (name, it, T))
 

@@ -45,6 +45,8 @@ def lib():
         L.gmo_pagerank.restype = None
         L.gmo_hop_dist.argtypes = [C.c_int32, i32p, i32p, C.c_int32, i32p, C.c_int, C.POINTER(C.c_int32)]
         L.gmo_hop_dist.restype = None
+        L.gmo_sssp.argtypes = [C.c_int32, i32p, i32p, i32p, C.c_int32, i32p, C.c_int, C.POINTER(C.c_int32)]
+        L.gmo_sssp.restype = None
         L.gmo_bfs_queue.argtypes = [C.c_int32, i32p, i32p, C.c_int32, i32p]
         L.gmo_bfs_queue.restype = None
         L.gmo_triangle_counting.argtypes = [C.c_int32, i32p, i32p, C.c_int]
@@ -154,6 +156,17 @@ def hop_dist(g, root=0, nthreads=0):
     lv = C.c_int32(0)
     L.gmo_hop_dist(g.N, g.begin, g.node_idx, root, dist, nthreads, C.byref(lv))
     return dist, lv.value
+
+
+def sssp(g, length, root=0, nthreads=0):
+    """sssp(G, dist, len, root): len[E] int32 indexed by forward edge slot.  Returns (dist, rounds)."""
+    L = lib()
+    length = np.ascontiguousarray(length, np.int32)
+    assert len(length) == g.M
+    dist = np.empty(max(g.N, 1), np.int32)[: g.N].copy()
+    rd = C.c_int32(0)
+    L.gmo_sssp(g.N, g.begin, g.node_idx, length, root, dist, nthreads, C.byref(rd))
+    return dist, rd.value
 
 
 def bfs_queue(g, root=0):

@@ -212,6 +212,82 @@ int ref_hop_dist(int32_t N, int32_t M, const int32_t* begin, const int32_t* node
     return 0;
 }
 
+/* ---- sssp: plain emission (apps/src/sssp.gm:1-30) against the reference runtime: hop_dist's loop with the
+ * edge property G_len[s_idx] (`Edge e = s.ToEdge()` is the neighbour iterator) ---- */
+int ref_sssp(int32_t N, int32_t M, const int32_t* begin, const int32_t* node_idx, const int32_t* G_len,
+             int32_t root_, int32_t* G_dist, int nthreads) {
+    gm_graph* gp = make_graph(N, M, begin, node_idx);
+    gm_graph& G = *gp;
+    node_t root = root_;
+    gm_rt_set_num_threads(nthreads);
+
+    gm_rt_initialize();
+    G.freeze();
+
+    bool fin = false;
+    bool* G_updated = gm_rt_allocate_bool(G.num_nodes(), gm_rt_thread_id());
+    bool* G_updated_nxt = gm_rt_allocate_bool(G.num_nodes(), gm_rt_thread_id());
+    int32_t* G_dist_nxt = gm_rt_allocate_int(G.num_nodes(), gm_rt_thread_id());
+
+    fin = false;
+    #pragma omp parallel for
+    for (node_t t0 = 0; t0 < G.num_nodes(); t0++) {
+        G_dist[t0] = (t0 == root) ? 0 : INT_MAX;
+        G_updated[t0] = (t0 == root) ? true : false;
+        G_dist_nxt[t0] = G_dist[t0];
+        G_updated_nxt[t0] = G_updated[t0];
+    }
+    while (!fin) {
+        bool __E8 = false;
+        fin = true;
+        __E8 = false;
+        #pragma omp parallel for schedule(dynamic,128)
+        for (node_t n = 0; n < G.num_nodes(); n++) {
+            if (G_updated[n]) {
+                for (edge_t s_idx = G.begin[n]; s_idx < G.begin[n + 1]; s_idx++) {
+                    node_t s = G.node_idx[s_idx];
+                    edge_t e;
+                    e = s_idx;
+                    { // argmin(argmax) - test and test-and-set
+                        int32_t dist_nxt_new = G_dist[n] + G_len[e];
+                        if (G_dist_nxt[s] > dist_nxt_new) {
+                            bool updated_nxt_arg = true;
+                            gm_spinlock_acquire_for_node(s);
+                            if (G_dist_nxt[s] > dist_nxt_new) {
+                                G_dist_nxt[s] = dist_nxt_new;
+                                G_updated_nxt[s] = updated_nxt_arg;
+                            }
+                            gm_spinlock_release_for_node(s);
+                        }
+                    }
+                }
+            }
+        }
+        #pragma omp parallel
+        {
+            bool __E8_prv = false;
+            #pragma omp for nowait
+            for (node_t t4 = 0; t4 < G.num_nodes(); t4++) {
+                G_dist[t4] = G_dist_nxt[t4];
+                G_updated[t4] = G_updated_nxt[t4];
+                G_updated_nxt[t4] = false;
+                __E8_prv = __E8_prv || G_updated[t4];
+            }
+            ATOMIC_OR(&__E8, __E8_prv);
+        }
+        fin = !__E8;
+    }
+    gm_rt_cleanup();
+    delete gp;
+    return 0;
+}
+
+/* (The reference also checks in one piece of generator output, apps/output_cpp/gm_graph/test/sssp_dijkstra.cc.
+ * It cannot serve as a second, pure-reference opinion on the distances: its priority map frees a node and
+ * then writes to it -- gm_mutatable_priority_map.h:1007-1013, heap-use-after-free under AddressSanitizer on
+ * the first removeMinKey_seq() -- so the cross-check of the sssp distances is scipy's Dijkstra instead,
+ * oracle/make_golden.py.) */
+
 /* ---- pure reference BFS: gm_bfs_template (gm_bfs_template.h:14-754) ---- */
 class ref_bfs_t : public gm_bfs_template<short, true, false, false, false>
 {

@@ -418,6 +418,44 @@ def test_triangle_counting_degree_oriented_path(gmx, monkeypatch):
     g.free()
 
 
+def test_sssp_golden_and_oracle(gmx, golden):
+    """gmx_sssp against the reference-pinned fixtures (every committed case) and the oracle on larger graphs
+    with adversarial lengths; unreachable = INT_MAX; bit-exact."""
+    for name, c in golden["cases"].items():
+        man = golden["manifest"]["rmat"].get(name) or golden["manifest"]["hand"].get(name[len("hand_"):])
+        g = gmx.Graph.upload(c["begin"], c["node_idx"], c["r_begin"], c["r_node_idx"])
+        dist, st = g.sssp(c["sssp_len"], man["root"])
+        assert np.array_equal(dist, c["sssp_dist"]), name
+        g.free()
+    rng = np.random.default_rng(99)
+    for scale, permute, hi in [(14, False, 101), (16, True, 101), (15, True, 2), (13, False, 100000)]:
+        og = po.rmat_graph(scale, permute=permute)
+        length = rng.integers(1, hi, og.M).astype(np.int32)
+        root = int(np.argmax(np.diff(og.begin)))
+        want = po.sssp(og, length, root)[0]
+        g = gmx.Graph.upload(og.begin, og.node_idx, None, None, flags=gmx.GMX_GRAPH_NO_REVERSE)
+        dist, st = g.sssp(length, root)
+        assert np.array_equal(dist, want), (scale, permute, hi)
+        assert st["iterations"] >= 1
+        # all lengths 1: sssp == hop_dist
+        ones = np.ones(og.M, np.int32)
+        assert np.array_equal(g.sssp(ones, root)[0], po.hop_dist(og, root)[0])
+        # root outside the graph / isolated vertices
+        assert np.all(g.sssp(length, og.N + 3)[0] == INT_MAX)
+        g.free()
+    # a long chain with a shortcut that only pays off late (many rounds, vertices re-enter the queue)
+    n = 2000
+    src = np.concatenate([np.arange(n - 1), [0]]).astype(np.int32)
+    dst = np.concatenate([np.arange(1, n), [n // 2]]).astype(np.int32)
+    og = po.graph_from_edges(n, src, dst)
+    length = np.ones(og.M, np.int32)
+    srcs = np.repeat(np.arange(n), np.diff(og.begin))
+    length[(srcs == 0) & (og.node_idx == n // 2)] = 900          # 0 -> n/2 directly costs 900, via the chain 1000
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    assert np.array_equal(g.sssp(length, 0)[0], po.sssp(og, length, 0)[0])
+    g.free()
+
+
 def test_reverse_edge_map(gmx, golden):
     """gmx_graph_reverse_edge_map = gm_graph's e_rev2idx: a one-to-one map from reverse slots to forward slots
     with swapped endpoints, copies of a repeated edge in order (what make_reverse_edges leaves after the sort)."""

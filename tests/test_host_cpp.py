@@ -4,6 +4,7 @@ the driver runs are GPU tests."""
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -64,7 +65,7 @@ def test_gm_graph_api(host_built, golden, tmp_path):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_APPS), reason="reference tree not present (GPU box)")
-@pytest.mark.parametrize("app", ["pagerank", "hop_dist", "triangle_counting"])
+@pytest.mark.parametrize("app", ["pagerank", "hop_dist", "triangle_counting", "sssp"])
 def test_reference_drivers_compile_unchanged(host_built, tmp_path, app):
     """Drop-in check: the REFERENCE's own driver sources (common_main.h + <app>_main.cc), untouched and
     compiled where they lie, build and link against this repo's gm.h / generated headers / libraries."""
@@ -99,6 +100,20 @@ def test_drivers_on_golden_bin(host_built, golden):
     assert [int(x) for x in re.findall(r"dist\[\d\] = (\d+)", out)] == c["dist"][:10].tolist()
     out = run_app("triangle_counting", src, "4", "/dev/null")
     assert int(re.search(r"number of triangles: (\d+)", out).group(1)) == m["tc_directed"]
+    # sssp: the driver draws the edge lengths from gm_rand32 in slot order (sssp_main.cc:33-34); same stream here
+    x = np.int32(np.uint32(2463534242).astype(np.int32))
+    lens = []
+    for _ in range(m["M"]):
+        x = np.int32(np.uint32(x) ^ np.uint32((int(np.uint32(x)) << 13) & 0xffffffff))
+        x = np.int32(x >> 17)
+        x = np.int32(np.uint32(x) ^ np.uint32((int(np.uint32(x)) << 5) & 0xffffffff))
+        lens.append(int(np.fmod(int(x), 100)) + 1)          # C's % truncates toward zero
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    g = po.Graph(m["N"], c["begin"].copy(), c["node_idx"].copy(), c["r_begin"].copy(), c["r_node_idx"].copy())
+    want = po.sssp(g, np.array(lens, np.int32), 0)[0]
+    out = run_app("sssp", src, "4", "/dev/null")
+    assert [int(x) for x in re.findall(r"dist\[\d\] = (\d+)", out)] == want[:10].tolist()
 
 
 @pytest.mark.gpu

@@ -46,6 +46,8 @@ def test_rmat_fixture_full(golden, name):
     dist, _ = po.hop_dist(g, m["root"])
     assert np.array_equal(dist, c["dist"])
     assert np.array_equal(po.bfs_queue(g, m["root"]), c["dist"])
+    assert np.array_equal(po.sssp(g, c["sssp_len"], m["root"])[0], c["sssp_dist"])
+    assert sha(c["sssp_len"]) == m["sha_sssp_len"] and sha(c["sssp_dist"]) == m["sha_sssp_dist"]
     assert po.triangle_counting(g) == m["tc_directed"]
     assert po.triangle_counting_merge(g) == m["tc_directed"]
     gs = po.symmetrize(g)
@@ -83,6 +85,7 @@ def test_hand_graphs(golden):
         assert it == m["pr_iters"] and np.array_equal(rank, c["rank"]), name
         dist, _ = po.hop_dist(g, m["root"])
         assert np.array_equal(dist, c["dist"]), name
+        assert np.array_equal(po.sssp(g, c["sssp_len"], m["root"])[0], c["sssp_dist"]), name
         assert po.triangle_counting(g) == m["tc"], name
         assert po.triangle_counting_merge(g) == m["tc"], name
 
