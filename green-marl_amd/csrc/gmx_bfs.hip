@@ -19,6 +19,7 @@
 // Integer only: bit-exact against the CPU result by construction.
 #include "gmx_internal.h"
 
+#include <float.h>
 #include <limits.h>
 #include <string.h>
 #include <rocprim/rocprim.hpp>
@@ -599,6 +600,225 @@ extern "C" int gmx_sssp(gmx_graph_t* g, gmx_node_t root, const int32_t* len_host
         stats->h2d_ms = hms;
         stats->edges_examined = (int64_t) edges;
         stats->vertices_reached = requeued + (root_ok ? 1 : 0);   // queue entries over all rounds (a vertex may re-enter)
+    }
+    for (hipEvent_t e : ev) (void) hipEventDestroy(e);
+    return GMX_OK;
+}
+
+// ------------------------------------------------------------------ avg_teen_cnt, conduct
+// Count-reductions over neighbours with an integer node property (/root/reference/apps/src/avg_teen_cnt.gm,
+// conduct.gm).  Both are "expand the out-edges of the vertices that pass a filter and do something per edge":
+// the selected vertices are queued (ballot-aggregated append), their out-degrees prefix-summed and the edges
+// cut by merge-path as in a top-down BFS level.  Integer arithmetic only; the final float is formed on the
+// host from the exact integers with the emitted expression, so results are bit-identical.
+//   MODE 0: cnt[dst] += 1                     (teen_cnt[n] = #in-neighbours passing the filter)
+//   MODE 1: total += (prop[dst] != num)       (conduct's Cross)
+template <int MODE>
+__global__ void __launch_bounds__(BFS_THREADS)
+edge_count_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx,
+                  const int32_t* __restrict__ cur_q, int64_t n, const int64_t* __restrict__ off, int64_t m,
+                  const int32_t* __restrict__ prop, int32_t num, int32_t* __restrict__ cnt,
+                  unsigned long long* __restrict__ total) {
+    __shared__ int64_t s_off[BFS_ITEMS + 2];
+    __shared__ int32_t s_row[BFS_ITEMS + 2];
+    __shared__ int64_t s_split[2][2];
+    const int tid = threadIdx.x;
+    if (tid < 2) {
+        int64_t dk = ((int64_t) blockIdx.x + tid) * BFS_ITEMS;
+        if (dk > n + m) dk = n + m;
+        int64_t lo = dk > m ? dk - m : 0, hi = dk < n ? dk : n;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (off[mid + 1] <= dk - mid - 1) lo = mid + 1; else hi = mid;
+        }
+        s_split[tid][0] = lo;
+        s_split[tid][1] = dk - lo;
+    }
+    __syncthreads();
+    const int64_t v0 = s_split[0][0], e0 = s_split[0][1], v1 = s_split[1][0], e1 = s_split[1][1];
+    const int nv = (int) (v1 - v0) + 1;
+    for (int i = tid; i < nv; i += BFS_THREADS) {
+        const int64_t vi = v0 + i;
+        s_off[i] = vi <= n ? off[vi < n ? vi : n] : m;
+        s_row[i] = vi < n ? begin[cur_q[vi]] : 0;
+    }
+    if (tid == 0) s_off[nv] = m + 1;
+    __syncthreads();
+    unsigned long long acc = 0;
+    for (int64_t x = e0 + tid; x < e1; x += BFS_THREADS) {
+        int lo = 0, hi = nv - 1;
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (s_off[mid] <= x) lo = mid; else hi = mid - 1;
+        }
+        const int32_t s = node_idx[(int64_t) s_row[lo] + (x - s_off[lo])];
+        if (MODE == 0) atomicAdd(&cnt[s], 1);
+        else acc += prop[s] != num ? 1 : 0;
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if ((tid & 63) == 0 && acc) atomicAdd(total, acc);
+    }
+}
+
+// filter: 0: 10 <= prop < 20 (teen), 1: prop == num
+__global__ void select_queue_kernel(const int32_t* __restrict__ prop, int64_t V, int filter, int32_t num,
+                                    int32_t* __restrict__ q, unsigned long long* __restrict__ qcount) {
+    int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    const int64_t vend = (V + 63) / 64 * 64;
+    for (; v < vend; v += stride) {
+        bool in = false;
+        if (v < V) {
+            const int32_t p = prop[v];
+            in = filter == 0 ? (p >= 10 && p < 20) : (p == num);
+        }
+        const unsigned long long mk = __ballot(in);
+        if (mk) {
+            const int lane = threadIdx.x & 63;
+            const int leader = __ffsll((long long) mk) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(qcount, (unsigned long long) __popcll(mk));
+            base = __shfl(base, leader, 64);
+            if (in) q[base + __popcll(mk & ((1ULL << lane) - 1))] = (int32_t) v;
+        }
+    }
+}
+
+// out[0] += sum of val[v] (or of the out-degree) over the vertices passing the test, out[1] += their number
+//   test 0: prop[v] > num   test 1: prop[v] == num   test 2: prop[v] != num
+__global__ void filtered_sum_kernel(const int32_t* __restrict__ prop, const int32_t* __restrict__ val, const int32_t* __restrict__ begin,
+                                    int64_t V, int test, int32_t num, unsigned long long* __restrict__ out) {
+    int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    unsigned long long s = 0, c = 0;
+    for (; v < V; v += stride) {
+        const int32_t p = prop[v];
+        const bool ok = test == 0 ? p > num : test == 1 ? p == num : p != num;
+        if (ok) {
+            s += (unsigned long long) (long long) (val ? val[v] : begin[v + 1] - begin[v]);
+            c++;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o, 64);
+        c += __shfl_down(c, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (s) atomicAdd(&out[0], s);
+        if (c) atomicAdd(&out[1], c);
+    }
+}
+
+// queue the vertices passing `filter`, then run edge_count_kernel<MODE> over their out-edges
+template <int MODE>
+static int expand_selected(gmx_graph* g, const int32_t* prop, int filter, int32_t num, int32_t* cnt, unsigned long long* total) {
+    const int64_t V = g->V;
+    dbuf<int32_t> q, deg;
+    dbuf<int64_t> off;
+    dbuf<unsigned long long> qcount;
+    dbuf<char> scan_tmp;
+    size_t scan_bytes = 0;
+    GMX_CHECK(q.alloc((size_t) V));
+    GMX_CHECK(deg.alloc((size_t) V));
+    GMX_CHECK(off.alloc((size_t) V + 2));
+    GMX_CHECK(qcount.alloc(1));
+    GMX_HIP(hipMemset(qcount.p, 0, sizeof(unsigned long long)));
+    hipLaunchKernelGGL(select_queue_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0, prop, V, filter, num, q.p, qcount.p);
+    unsigned long long nq = 0;
+    GMX_HIP(hipMemcpy(&nq, qcount.p, sizeof(nq), hipMemcpyDeviceToHost));
+    if (nq == 0) return GMX_OK;
+    hipLaunchKernelGGL(bfs_degree_kernel, dim3(grid_for((int64_t) nq)), dim3(BFS_THREADS), 0, 0, g->begin.p, q.p, (int64_t) nq, deg.p);
+    GMX_HIP(rocprim::inclusive_scan(nullptr, scan_bytes, deg.p, off.p + 1, (size_t) nq, rocprim::plus<int64_t>(), 0));
+    GMX_CHECK(scan_tmp.alloc(scan_bytes));
+    GMX_HIP(rocprim::inclusive_scan(scan_tmp.p, scan_bytes, deg.p, off.p + 1, (size_t) nq, rocprim::plus<int64_t>(), 0));
+    GMX_HIP(hipMemsetAsync(off.p, 0, sizeof(int64_t), 0));
+    int64_t m_f = 0;
+    GMX_HIP(hipMemcpy(&m_f, off.p + nq, sizeof(int64_t), hipMemcpyDeviceToHost));
+    const int64_t nb = ((int64_t) nq + m_f + BFS_ITEMS - 1) / BFS_ITEMS;
+    if (nb > 0)
+        hipLaunchKernelGGL(edge_count_kernel<MODE>, dim3((unsigned) nb), dim3(BFS_THREADS), 0, 0, g->begin.p, g->node_idx.p,
+                           (const int32_t*) q.p, (int64_t) nq, (const int64_t*) off.p, m_f, prop, num, cnt, total);
+    GMX_HIP(hipGetLastError());
+    return GMX_OK;
+}
+
+extern "C" int gmx_avg_teen_cnt(gmx_graph_t* g, const int32_t* age_host, int32_t K, int32_t* teen_cnt_host, float* avg,
+                                gmx_stats_t* stats) {
+    GMX_REQUIRE(g && avg && (teen_cnt_host || g->V == 0) && (age_host || g->V == 0), "NULL argument");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    *avg = 0;
+    const int64_t V = g->V;
+    if (V == 0) return GMX_OK;
+    dbuf<int32_t> age, cnt;
+    dbuf<unsigned long long> acc;
+    GMX_CHECK(age.alloc((size_t) V));
+    GMX_CHECK(cnt.alloc((size_t) V));
+    GMX_CHECK(acc.alloc(2));
+    hipEvent_t ev[2];
+    for (hipEvent_t& e : ev) GMX_HIP(hipEventCreate(&e));
+    GMX_HIP(hipMemcpy(age.p, age_host, sizeof(int32_t) * (size_t) V, hipMemcpyHostToDevice));
+    GMX_HIP(hipEventRecord(ev[0], 0));
+    GMX_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * (size_t) V, 0));
+    GMX_HIP(hipMemsetAsync(acc.p, 0, 2 * sizeof(unsigned long long), 0));
+    // n.teen_cnt = Count(t: n.InNbrs)(t.age >= 10 && t.age < 20): one increment per out-edge of a teen
+    GMX_CHECK(expand_selected<0>(g, age.p, 0, 0, cnt.p, nullptr));
+    // Avg(n: G.Nodes)(n.age > K){n.teen_cnt}: int32 sum, int64 count (gm_syntax_sugar2.cc:264-296)
+    hipLaunchKernelGGL(filtered_sum_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, (const int32_t*) age.p, (const int32_t*) cnt.p,
+                       (const int32_t*) nullptr, V, 0, K, acc.p);
+    GMX_HIP(hipEventRecord(ev[1], 0));
+    unsigned long long h[2];
+    GMX_HIP(hipMemcpy(h, acc.p, sizeof(h), hipMemcpyDeviceToHost));
+    GMX_HIP(hipMemcpy(teen_cnt_host, cnt.p, sizeof(int32_t) * (size_t) V, hipMemcpyDeviceToHost));
+    const int32_t S = (int32_t) (uint32_t) h[0];          // the emitted sum is an int32 and wraps like one
+    const int64_t n = (int64_t) h[1];
+    const double a = (0 == n) ? ((float) (0.000000)) : (S / ((double) n));
+    *avg = (float) a;
+    if (stats) {
+        float ms = 0;
+        (void) hipEventElapsedTime(&ms, ev[0], ev[1]);
+        stats->iterations = 1;
+        stats->kernel_ms = ms;
+    }
+    for (hipEvent_t e : ev) (void) hipEventDestroy(e);
+    return GMX_OK;
+}
+
+extern "C" int gmx_conduct(gmx_graph_t* g, const int32_t* member_host, int32_t num, float* result, gmx_stats_t* stats) {
+    GMX_REQUIRE(g && result && (member_host || g->V == 0), "NULL argument");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    *result = 0;
+    const int64_t V = g->V;
+    unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+    hipEvent_t ev[2];
+    for (hipEvent_t& e : ev) GMX_HIP(hipEventCreate(&e));
+    if (V > 0) {
+        dbuf<int32_t> member;
+        dbuf<unsigned long long> acc;   // [0,1] Din + count, [2,3] Dout + count, [4] Cross
+        GMX_CHECK(member.alloc((size_t) V));
+        GMX_CHECK(acc.alloc(6));
+        GMX_HIP(hipMemcpy(member.p, member_host, sizeof(int32_t) * (size_t) V, hipMemcpyHostToDevice));
+        GMX_HIP(hipEventRecord(ev[0], 0));
+        GMX_HIP(hipMemsetAsync(acc.p, 0, 6 * sizeof(unsigned long long), 0));
+        hipLaunchKernelGGL(filtered_sum_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, (const int32_t*) member.p, (const int32_t*) nullptr,
+                           (const int32_t*) g->begin.p, V, 1, num, acc.p);
+        hipLaunchKernelGGL(filtered_sum_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, (const int32_t*) member.p, (const int32_t*) nullptr,
+                           (const int32_t*) g->begin.p, V, 2, num, acc.p + 2);
+        GMX_CHECK(expand_selected<1>(g, member.p, 1, num, nullptr, acc.p + 4));
+        GMX_HIP(hipEventRecord(ev[1], 0));
+        GMX_HIP(hipMemcpy(h, acc.p, sizeof(h), hipMemcpyDeviceToHost));
+    }
+    const int32_t Din = (int32_t) (uint32_t) h[0], Dout = (int32_t) (uint32_t) h[2], Cross = (int32_t) (uint32_t) h[4];
+    const float m = (float) ((Din < Dout) ? Din : Dout);
+    if (m == 0) *result = (Cross == 0) ? ((float) (0.000000)) : FLT_MAX;
+    else *result = Cross / m;
+    if (stats && V > 0) {
+        float ms = 0;
+        (void) hipEventElapsedTime(&ms, ev[0], ev[1]);
+        stats->iterations = 1;
+        stats->kernel_ms = ms;
     }
     for (hipEvent_t e : ev) (void) hipEventDestroy(e);
     return GMX_OK;

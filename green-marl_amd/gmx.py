@@ -43,7 +43,7 @@ EXPORTS = [
     "gmx_last_error", "gmx_device_count", "gmx_set_device", "gmx_device_info",
     "gmx_graph_upload", "gmx_graph_from_edges", "gmx_graph_create_rmat", "gmx_graph_free", "gmx_graph_symmetrize",
     "gmx_graph_num_nodes", "gmx_graph_num_edges", "gmx_graph_download",
-    "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_sssp", "gmx_triangle_counting", "gmx_triangle_counting_part", "gmx_graph_reverse_edge_map",
+    "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_sssp", "gmx_avg_teen_cnt", "gmx_conduct", "gmx_triangle_counting", "gmx_triangle_counting_part", "gmx_graph_reverse_edge_map",
     "gmx_bfs_create", "gmx_bfs_free", "gmx_bfs_start", "gmx_bfs_step_begin", "gmx_bfs_found_bitmap", "gmx_bfs_step_end",
     "gmx_bfs_download",
     "gmx_pr_create", "gmx_pr_free", "gmx_pr_reset", "gmx_pr_step", "gmx_pr_contrib_slice",
@@ -93,6 +93,8 @@ def lib():
         L.gmx_hop_dist.argtypes = [vp, i32, vp, C.POINTER(Stats)]
         L.gmx_triangle_counting.argtypes = [vp, C.POINTER(i64), C.POINTER(Stats)]
         L.gmx_sssp.argtypes = [vp, i32, vp, vp, C.POINTER(Stats)]
+        L.gmx_avg_teen_cnt.argtypes = [vp, vp, i32, vp, C.POINTER(C.c_float), C.POINTER(Stats)]
+        L.gmx_conduct.argtypes = [vp, vp, i32, C.POINTER(C.c_float), C.POINTER(Stats)]
         L.gmx_graph_reverse_edge_map.argtypes = [vp, vp]
         L.gmx_triangle_counting_part.argtypes = [vp, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(Stats)]
         L.gmx_bfs_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
@@ -272,6 +274,24 @@ class Graph:
         st = Stats()
         _ck(lib().gmx_sssp(self._h, int(root), length.ctypes.data if self.E else None, dist.ctypes.data, C.byref(st)))
         return dist, st.as_dict()
+
+    def avg_teen_cnt(self, age, K):
+        """avg_teen_cnt(G, age, teen_cnt, K) -- returns (avg float32, teen_cnt[int32], stats)."""
+        age = _i32(age)
+        assert len(age) == self.V
+        cnt = np.zeros(max(self.V, 1), np.int32)[:self.V].copy()
+        avg, st = C.c_float(0), Stats()
+        _ck(lib().gmx_avg_teen_cnt(self._h, age.ctypes.data if self.V else None, int(K), cnt.ctypes.data if self.V else None,
+                                   C.byref(avg), C.byref(st)))
+        return np.float32(avg.value), cnt, st.as_dict()
+
+    def conduct(self, member, num):
+        """conduct(G, member, num) -- returns (float32, stats)."""
+        member = _i32(member)
+        assert len(member) == self.V
+        res, st = C.c_float(0), Stats()
+        _ck(lib().gmx_conduct(self._h, member.ctypes.data if self.V else None, int(num), C.byref(res), C.byref(st)))
+        return np.float32(res.value), st.as_dict()
 
     def reverse_edge_map(self):
         """e_rev2idx: forward slot mirrored by each reverse-CSR slot."""

@@ -145,6 +145,12 @@ int gmx_bfs_download(gmx_bfs_t* b, int32_t* dist_host, gmx_stats_t* stats);
  * stats: iterations = relaxation rounds, h2d_ms = upload of len, vertices_reached = queue entries over all rounds. */
 int gmx_sssp(gmx_graph_t* g, gmx_node_t root, const int32_t* len_host, int32_t* dist_host, gmx_stats_t* stats);
 
+/* avg_teen_cnt(G, age, teen_cnt, K) (apps/src/avg_teen_cnt.gm; driver avg_teen_cnt_main.cc:24) and
+ * conduct(G, member, num) (apps/src/conduct.gm; driver conduct_main.cc:45): count-reductions over neighbours
+ * with the caller's int32 node property; integers exact, the returned float formed by the emitted expression. */
+int gmx_avg_teen_cnt(gmx_graph_t* g, const int32_t* age_host, int32_t K, int32_t* teen_cnt_host, float* avg, gmx_stats_t* stats);
+int gmx_conduct(gmx_graph_t* g, const int32_t* member_host, int32_t num, float* result, gmx_stats_t* stats);
+
 /* triangle_counting(G) with the emitted multiplicity rule. */
 int gmx_triangle_counting(gmx_graph_t* g, int64_t* count, gmx_stats_t* stats);
 /* Multi-GPU form (replicated CSR, final all-reduce of int64): the count contributed by part

@@ -6,6 +6,7 @@
 #include "gm_oracle.h"
 
 #include <limits.h>
+#include <float.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -284,6 +285,89 @@ void gmo_pagerank(gmo_node_t numNodes,
     free(G_pg_rank_nxt);
     if (iters_out) *iters_out = cnt;
     if (diff_out) *diff_out = diff;
+}
+
+/* ------------------------------------------------------------------ */
+/* avg_teen_cnt -- restated emission:            */
+/*   source apps/src/avg_teen_cnt.gm:1-13                              */
+/*   Count(t: n.InNbrs)(filter) -> Sum of 1 under the filter, sequential*/
+/*   inner loop over r_begin/r_node_idx (gm_cpp_gen_foreach.cc:161,286)*/
+/*   Avg(n)(filter){Int} -> int32 sum __S, int64 count _cnt, then      */
+/*   _avg = (0 == _cnt) ? 0 : __S / (double) _cnt                      */
+/*       (src/opt/gm_syntax_sugar2.cc:264-296,421-436), (Float) cast.  */
+/*   Scalar reductions: thread-private partials + ATOMIC_ADD           */
+/*       (gm_cpp_opt_reduce_scalar.cc:141-257) -- integer, so exact.   */
+/* ------------------------------------------------------------------ */
+float gmo_avg_teen_cnt(gmo_node_t numNodes, const gmo_edge_t* r_begin, const gmo_node_t* r_node_idx,
+                       const int32_t* G_age, int32_t* G_teen_cnt, int32_t K, int nthreads) {
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    float avg = 0;
+    double _avg4 = 0;
+    int64_t _cnt3 = 0;
+    int32_t __S2 = 0;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 128)
+    for (gmo_node_t n = 0; n < numNodes; n++) {
+        int32_t __S1 = 0;
+        for (gmo_edge_t t_idx = r_begin[n]; t_idx < r_begin[n + 1]; t_idx++) {
+            gmo_node_t t = r_node_idx[t_idx];
+            if ((G_age[t] >= 10) && (G_age[t] < 20)) __S1 = __S1 + 1;
+        }
+        G_teen_cnt[n] = __S1;
+    }
+#pragma omp parallel num_threads(nthreads)
+    {
+        int32_t __S2_prv = 0;
+        int64_t _cnt3_prv = 0;
+#pragma omp for nowait
+        for (gmo_node_t n0 = 0; n0 < numNodes; n0++) {
+            if (G_age[n0] > K) {
+                __S2_prv = __S2_prv + G_teen_cnt[n0];
+                _cnt3_prv = _cnt3_prv + 1;
+            }
+        }
+        __atomic_fetch_add(&_cnt3, _cnt3_prv, __ATOMIC_SEQ_CST);
+        __atomic_fetch_add(&__S2, __S2_prv, __ATOMIC_SEQ_CST);
+    }
+    _avg4 = (0 == _cnt3) ? ((float) (0.000000)) : (__S2 / ((double) _cnt3));
+    avg = (float) _avg4;
+    return avg;
+}
+
+/* ------------------------------------------------------------------ */
+/* conduct -- restated emission:                 */
+/*   source apps/src/conduct.gm:1-14.  Three Int (int32) sums:         */
+/*   degrees of the members, of the non-members (u.Degree() ->         */
+/*   begin[u+1]-begin[u], gm_cpplib_gen.cc:456-472) and the member ->  */
+/*   non-member edges; Float m = min(Din, Dout) (coercion to float,    */
+/*   src/frontend/gm_coercion.cc:6-37); m == 0 -> 0 or +INF = FLT_MAX  */
+/*   (gm_cpp_gen.cc:1773-1799); else (float) Cross / m.                */
+/* ------------------------------------------------------------------ */
+float gmo_conduct(gmo_node_t numNodes, const gmo_edge_t* begin, const gmo_node_t* node_idx,
+                  const int32_t* G_member, int32_t num, int nthreads) {
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    int32_t Din = 0, Dout = 0, Cross = 0;
+#pragma omp parallel num_threads(nthreads)
+    {
+        int32_t din_prv = 0, dout_prv = 0, cross_prv = 0;
+#pragma omp for nowait schedule(dynamic, 128)
+        for (gmo_node_t u = 0; u < numNodes; u++) {
+            if (G_member[u] == num) {
+                din_prv = din_prv + (begin[u + 1] - begin[u]);
+                int32_t __S3 = 0;
+                for (gmo_edge_t j_idx = begin[u]; j_idx < begin[u + 1]; j_idx++) {
+                    gmo_node_t j = node_idx[j_idx];
+                    if (G_member[j] != num) __S3 = __S3 + 1;
+                }
+                cross_prv = cross_prv + __S3;
+            } else dout_prv = dout_prv + (begin[u + 1] - begin[u]);
+        }
+        __atomic_fetch_add(&Din, din_prv, __ATOMIC_SEQ_CST);
+        __atomic_fetch_add(&Dout, dout_prv, __ATOMIC_SEQ_CST);
+        __atomic_fetch_add(&Cross, cross_prv, __ATOMIC_SEQ_CST);
+    }
+    float m = (float) ((Din < Dout) ? Din : Dout);
+    if (m == 0) return (Cross == 0) ? ((float) (0.000000)) : FLT_MAX;
+    return Cross / m;
 }
 
 /* ------------------------------------------------------------------ */

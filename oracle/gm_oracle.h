@@ -85,6 +85,13 @@ void gmo_pagerank(gmo_node_t N,
                   double e, double d, int32_t max_iter, double* rank,
                   int nthreads, int32_t* iters_out, double* diff_out);
 
+/* ---- emitted kernels: avg_teen_cnt (apps/src/avg_teen_cnt.gm:1-13) and conduct (apps/src/conduct.gm:1-14),
+ * count-reductions over in-/out-neighbours with an integer node property. */
+float gmo_avg_teen_cnt(gmo_node_t N, const gmo_edge_t* r_begin, const gmo_node_t* r_node_idx,
+                       const int32_t* age, int32_t* teen_cnt, int32_t K, int nthreads);
+float gmo_conduct(gmo_node_t N, const gmo_edge_t* begin, const gmo_node_t* node_idx,
+                  const int32_t* member, int32_t num, int nthreads);
+
 /* ---- emitted kernel: sssp (apps/src/sssp.gm:1-30): hop_dist with the edge property
  * len[E] (indexed by forward edge slot) in place of 1.  dist[v] = shortest path length, INT_MAX unreachable. */
 void gmo_sssp(gmo_node_t N,

@@ -56,6 +56,10 @@ def ref_lib():
                                C.c_int, C.POINTER(C.c_int32)]
     R.ref_hop_dist.argtypes = [C.c_int32, C.c_int32, i32p, i32p, C.c_int32, i32p, C.c_int]
     R.ref_sssp.argtypes = [C.c_int32, C.c_int32, i32p, i32p, i32p, C.c_int32, i32p, C.c_int]
+    R.ref_avg_teen_cnt.argtypes = [C.c_int32, C.c_int32, i32p, i32p, i32p, i32p, C.c_int32, C.c_int]
+    R.ref_avg_teen_cnt.restype = C.c_float
+    R.ref_conduct.argtypes = [C.c_int32, C.c_int32, i32p, i32p, i32p, C.c_int32, C.c_int]
+    R.ref_conduct.restype = C.c_float
     R.ref_bfs_levels.argtypes = [C.c_int32, C.c_int32, i32p, i32p, C.c_int32, i32p, C.c_int, C.c_int]
     R.ref_triangle_counting.argtypes = [C.c_int32, C.c_int32, i32p, i32p, C.c_int]
     R.ref_triangle_counting.restype = C.c_int64
@@ -131,6 +135,38 @@ def check_sssp(R, name, g, root, salt):
     return length, dist_r
 
 
+def node_props(N, salt):
+    """Node properties for avg_teen_cnt (ages 0..39) and conduct (4 groups 10/20/30/40 % as conduct_main.cc:30-38)."""
+    rng = np.random.default_rng(7919 * salt + N)
+    age = rng.integers(0, 40, max(N, 1)).astype(np.int32)[:N]
+    r = rng.integers(0, 100, max(N, 1))[:N]
+    member = np.where(r < 10, 0, np.where(r < 30, 1, np.where(r < 60, 2, 3))).astype(np.int32)
+    return age, member
+
+
+def check_counts(R, name, g, salt):
+    """avg_teen_cnt and conduct: oracle restatement == emission on the reference runtime (integers and the
+    final float bit for bit), for K in {5, 25, 100} and every group."""
+    age, member = node_props(g.N, salt)
+    out = {"age": age, "member": member}
+    avgs = []
+    for K in (5, 25, 100):
+        cnt_r = e32(g.N)
+        avg_r = R.ref_avg_teen_cnt(g.N, g.M, g.begin, g.node_idx, age, cnt_r, K, 4)
+        avg_o, cnt_o = po.avg_teen_cnt(g, age, K, nthreads=8)
+        assert np.array_equal(cnt_o, cnt_r), (name, "teen_cnt")
+        assert np.float32(avg_r).tobytes() == np.float32(avg_o).tobytes(), (name, "avg", K, avg_r, avg_o)
+        avgs.append(float(np.float32(avg_r)))
+        out["teen_cnt"] = cnt_r
+    cs = []
+    for num in range(5):   # group 4 is empty: exercises the m == 0 branch
+        c_r = R.ref_conduct(g.N, g.M, g.begin, g.node_idx, member, num, 4)
+        c_o = po.conduct(g, member, num, nthreads=8)
+        assert np.float32(c_r).tobytes() == np.float32(c_o).tobytes(), (name, "conduct", num, c_r, c_o)
+        cs.append(float(np.float32(c_r)))
+    return out, avgs, cs
+
+
 def check_oracle_on(R, name, N, begin, raw_or_sorted, pr_args=(0.001, 0.85, 100), root=0, tc=True):
     """Run reference + oracle on one CSR; assert agreement; return results."""
     g = po.Graph(N, begin.copy(), raw_or_sorted.copy()).prepare()
@@ -192,6 +228,7 @@ def main():
                                                 pr_args=(1e-300, 0.85, 20), root=root, tc=False)
         assert it20 == 20
         sssp_len, sssp_dist = check_sssp(R, name, g, root, scale * 2 + perm)
+        props, teen_avgs, conducts = check_counts(R, name, g, scale * 2 + perm)
         # symmetrised graph for the TC measurement config
         gs = po.symmetrize(g)
         Ts = None
@@ -222,13 +259,16 @@ def main():
                  "sha_begin": sha(begin), "sha_raw_node_idx": sha(raw), "sha_node_idx": sha(snode),
                  "sha_r_begin": sha(rb), "sha_r_node_idx": sha(rn), "sha_dist": sha(dist),
                  "sha_rank_f64": sha(rank), "sha_rank20_f64": sha(rank20),
+                 "props_salt": scale * 2 + perm, "teen_avg_K5_K25_K100": teen_avgs, "conduct_0_4": conducts,
+                 "sha_teen_cnt": sha(props["teen_cnt"]), "sha_age": sha(props["age"]), "sha_member": sha(props["member"]),
                  "sssp_salt": scale * 2 + perm, "sha_sssp_len": sha(sssp_len), "sha_sssp_dist": sha(sssp_dist),
                  "sssp_reached": int((sssp_dist != INT_MAX).sum()), "sssp_max": int(sssp_dist[sssp_dist != INT_MAX].max()),
                  "rank_sum": float(rank.sum()), "rank_head": [float(x) for x in rank[:4]]}
         manifest["rmat"][name] = entry
         if scale <= 10:   # small enough to commit in full
             fixtures[name] = dict(begin=begin, raw_node_idx=raw, node_idx=snode, r_begin=rb, r_node_idx=rn,
-                                  rank=rank, rank20=rank20, dist=dist, sssp_len=sssp_len, sssp_dist=sssp_dist)
+                                  rank=rank, rank20=rank20, dist=dist, sssp_len=sssp_len, sssp_dist=sssp_dist,
+                                  age=props["age"], member=props["member"], teen_cnt=props["teen_cnt"])
         print("%s: pinned (iters=%d, reached=%d, T=%s, Tsym=%s)" % (name, it, entry["reached"], T, Ts))
 
     # ---- 3. hand graphs ----
@@ -251,9 +291,12 @@ def main():
         begin, raw = po.csr_from_edges(N, src, dst)
         g, rank, it, dist, T = check_oracle_on(R, name, N, begin, raw, root=root, tc=True)
         sssp_len, sssp_dist = check_sssp(R, name, g, root, len(name))
+        props, teen_avgs, conducts = check_counts(R, name, g, len(name))
         fixtures["hand_" + name] = dict(begin=begin, raw_node_idx=raw, node_idx=g.node_idx, r_begin=g.r_begin,
-                                        r_node_idx=g.r_node_idx, rank=rank, dist=dist, sssp_len=sssp_len, sssp_dist=sssp_dist)
-        manifest["hand"][name] = {"N": N, "M": len(edges), "root": root, "pr_iters": it, "tc": T}
+                                        r_node_idx=g.r_node_idx, rank=rank, dist=dist, sssp_len=sssp_len, sssp_dist=sssp_dist,
+                                        age=props["age"], member=props["member"], teen_cnt=props["teen_cnt"])
+        manifest["hand"][name] = {"N": N, "M": len(edges), "root": root, "pr_iters": it, "tc": T,
+                                  "teen_avg_K5_K25_K100": teen_avgs, "conduct_0_4": conducts}
         print("hand %s: pinned (iters=%d T=%d)" % (name, it, T))
 
     # ---- 4. binary format ----

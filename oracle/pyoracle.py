@@ -47,6 +47,10 @@ def lib():
         L.gmo_hop_dist.restype = None
         L.gmo_sssp.argtypes = [C.c_int32, i32p, i32p, i32p, C.c_int32, i32p, C.c_int, C.POINTER(C.c_int32)]
         L.gmo_sssp.restype = None
+        L.gmo_avg_teen_cnt.argtypes = [C.c_int32, i32p, i32p, i32p, i32p, C.c_int32, C.c_int]
+        L.gmo_avg_teen_cnt.restype = C.c_float
+        L.gmo_conduct.argtypes = [C.c_int32, i32p, i32p, i32p, C.c_int32, C.c_int]
+        L.gmo_conduct.restype = C.c_float
         L.gmo_bfs_queue.argtypes = [C.c_int32, i32p, i32p, C.c_int32, i32p]
         L.gmo_bfs_queue.restype = None
         L.gmo_triangle_counting.argtypes = [C.c_int32, i32p, i32p, C.c_int]
@@ -167,6 +171,20 @@ def sssp(g, length, root=0, nthreads=0):
     rd = C.c_int32(0)
     L.gmo_sssp(g.N, g.begin, g.node_idx, length, root, dist, nthreads, C.byref(rd))
     return dist, rd.value
+
+
+def avg_teen_cnt(g, age, K, nthreads=0):
+    """avg_teen_cnt(G, age, teen_cnt, K) -> (avg as float32, teen_cnt[int32])."""
+    age = np.ascontiguousarray(age, np.int32)
+    cnt = np.empty(max(g.N, 1), np.int32)[: g.N].copy()
+    avg = lib().gmo_avg_teen_cnt(g.N, g.r_begin, g.r_node_idx, age, cnt, int(K), nthreads)
+    return np.float32(avg), cnt
+
+
+def conduct(g, member, num, nthreads=0):
+    """conduct(G, member, num) -> float32."""
+    member = np.ascontiguousarray(member, np.int32)
+    return np.float32(lib().gmo_conduct(g.N, g.begin, g.node_idx, member, int(num), nthreads))
 
 
 def bfs_queue(g, root=0):

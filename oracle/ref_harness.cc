@@ -16,6 +16,7 @@
  * checks of hop_dist and triangle_counting.
  */
 #include <limits.h>
+#include <float.h>
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
@@ -280,6 +281,101 @@ int ref_sssp(int32_t N, int32_t M, const int32_t* begin, const int32_t* node_idx
     gm_rt_cleanup();
     delete gp;
     return 0;
+}
+
+/* ---- avg_teen_cnt / conduct: plain emissions (apps/src/avg_teen_cnt.gm, conduct.gm) against the reference
+ * runtime (gm_graph reverse edges, ATOMIC_ADD); see oracle/gm_oracle.c for the generator rules followed ---- */
+float ref_avg_teen_cnt(int32_t N, int32_t M, const int32_t* begin, const int32_t* node_idx,
+                       const int32_t* G_age, int32_t* G_teen_cnt, int32_t K, int nthreads) {
+    gm_graph* gp = make_graph(N, M, begin, node_idx);
+    gm_graph& G = *gp;
+    gm_rt_set_num_threads(nthreads);
+    gm_rt_initialize();
+    G.freeze();
+    G.make_reverse_edges();
+
+    float avg = 0;
+    double _avg4 = 0;
+    int64_t _cnt3 = 0;
+    int32_t __S2 = 0;
+    #pragma omp parallel for schedule(dynamic,128)
+    for (node_t n = 0; n < G.num_nodes(); n++) {
+        int32_t __S1 = 0;
+        for (edge_t t_idx = G.r_begin[n]; t_idx < G.r_begin[n + 1]; t_idx++) {
+            node_t t = G.r_node_idx[t_idx];
+            if ((G_age[t] >= 10) && (G_age[t] < 20)) __S1 = __S1 + 1;
+        }
+        G_teen_cnt[n] = __S1;
+    }
+    #pragma omp parallel
+    {
+        int32_t __S2_prv = 0;
+        int64_t _cnt3_prv = 0;
+        #pragma omp for nowait
+        for (node_t n0 = 0; n0 < G.num_nodes(); n0++) {
+            if (G_age[n0] > K) {
+                __S2_prv = __S2_prv + G_teen_cnt[n0];
+                _cnt3_prv = _cnt3_prv + 1;
+            }
+        }
+        ATOMIC_ADD<int64_t>(&_cnt3, _cnt3_prv);
+        ATOMIC_ADD<int32_t>(&__S2, __S2_prv);
+    }
+    _avg4 = (0 == _cnt3) ? ((float)(0.000000)) : (__S2 / ((double)_cnt3));
+    avg = (float)_avg4;
+    gm_rt_cleanup();
+    delete gp;
+    return avg;
+}
+
+float ref_conduct(int32_t N, int32_t M, const int32_t* begin, const int32_t* node_idx,
+                  const int32_t* G_member, int32_t num, int nthreads) {
+    gm_graph* gp = make_graph(N, M, begin, node_idx);
+    gm_graph& G = *gp;
+    gm_rt_set_num_threads(nthreads);
+    gm_rt_initialize();
+    G.freeze();
+
+    int32_t Din = 0, Dout = 0, Cross = 0;
+    #pragma omp parallel
+    {
+        int32_t Din_prv = 0;
+        #pragma omp for nowait
+        for (node_t u = 0; u < G.num_nodes(); u++)
+            if (G_member[u] == num) Din_prv = Din_prv + (G.begin[u + 1] - G.begin[u]);
+        ATOMIC_ADD<int32_t>(&Din, Din_prv);
+    }
+    #pragma omp parallel
+    {
+        int32_t Dout_prv = 0;
+        #pragma omp for nowait
+        for (node_t u0 = 0; u0 < G.num_nodes(); u0++)
+            if (G_member[u0] != num) Dout_prv = Dout_prv + (G.begin[u0 + 1] - G.begin[u0]);
+        ATOMIC_ADD<int32_t>(&Dout, Dout_prv);
+    }
+    #pragma omp parallel
+    {
+        int32_t Cross_prv = 0;
+        #pragma omp for nowait schedule(dynamic,128)
+        for (node_t u1 = 0; u1 < G.num_nodes(); u1++) {
+            if (G_member[u1] == num) {
+                int32_t __S3 = 0;
+                for (edge_t j_idx = G.begin[u1]; j_idx < G.begin[u1 + 1]; j_idx++) {
+                    node_t j = G.node_idx[j_idx];
+                    if (G_member[j] != num) __S3 = __S3 + 1;
+                }
+                Cross_prv = Cross_prv + __S3;
+            }
+        }
+        ATOMIC_ADD<int32_t>(&Cross, Cross_prv);
+    }
+    float m = (float)((Din < Dout) ? Din : Dout);
+    float ret;
+    if (m == 0) ret = (Cross == 0) ? ((float)(0.000000)) : FLT_MAX;
+    else ret = Cross / m;
+    gm_rt_cleanup();
+    delete gp;
+    return ret;
 }
 
 /* (The reference also checks in one piece of generator output, apps/output_cpp/gm_graph/test/sssp_dijkstra.cc.

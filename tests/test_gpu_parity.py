@@ -456,6 +456,42 @@ def test_sssp_golden_and_oracle(gmx, golden):
     g.free()
 
 
+def test_avg_teen_cnt_and_conduct(gmx, golden):
+    """gmx_avg_teen_cnt / gmx_conduct against the reference-pinned fixtures and the oracle: the integer arrays
+    exactly, the returned float32 bit for bit."""
+    for name, c in golden["cases"].items():
+        man = golden["manifest"]["rmat"].get(name) or golden["manifest"]["hand"].get(name[len("hand_"):])
+        g = gmx.Graph.upload(c["begin"], c["node_idx"], c["r_begin"], c["r_node_idx"])
+        for K, want in zip((5, 25, 100), man["teen_avg_K5_K25_K100"]):
+            avg, cnt, _ = g.avg_teen_cnt(c["age"], K)
+            assert np.array_equal(cnt, c["teen_cnt"]), name
+            assert np.float32(avg).tobytes() == np.float32(want).tobytes(), (name, K, avg, want)
+        for num, want in enumerate(man["conduct_0_4"]):
+            got, _ = g.conduct(c["member"], num)
+            assert np.float32(got).tobytes() == np.float32(want).tobytes(), (name, num, got, want)
+        g.free()
+    rng = np.random.default_rng(5)
+    for scale, permute in [(14, False), (17, True)]:
+        og = po.rmat_graph(scale, permute=permute)
+        g = gmx.Graph.upload(og.begin, og.node_idx, None, None, flags=gmx.GMX_GRAPH_NO_REVERSE)
+        for age in (rng.integers(0, 40, og.N).astype(np.int32), np.full(og.N, 10, np.int32), np.full(og.N, 50, np.int32)):
+            for K in (5, 30):
+                avg, cnt, _ = g.avg_teen_cnt(age, K)
+                want_avg, want_cnt = po.avg_teen_cnt(og, age, K)
+                assert np.array_equal(cnt, want_cnt)
+                assert np.float32(avg).tobytes() == np.float32(want_avg).tobytes()
+        for member in (rng.integers(0, 4, og.N).astype(np.int32), np.zeros(og.N, np.int32)):
+            for num in (0, 1, 3, 7):
+                assert np.float32(g.conduct(member, num)[0]).tobytes() == np.float32(po.conduct(og, member, num)).tobytes()
+        g.free()
+    # group with outgoing crossing edges but no edges counted on the smaller side: m == 0 and Cross > 0 -> FLT_MAX
+    og = po.graph_from_edges(3, np.array([0], np.int32), np.array([1], np.int32))
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    member = np.array([1, 0, 0], np.int32)
+    assert np.float32(g.conduct(member, 1)[0]) == np.float32(po.conduct(og, member, 1)) == np.finfo(np.float32).max
+    g.free()
+
+
 def test_reverse_edge_map(gmx, golden):
     """gmx_graph_reverse_edge_map = gm_graph's e_rev2idx: a one-to-one map from reverse slots to forward slots
     with swapped endpoints, copies of a repeated edge in order (what make_reverse_edges leaves after the sort)."""

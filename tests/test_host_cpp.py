@@ -65,7 +65,7 @@ def test_gm_graph_api(host_built, golden, tmp_path):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_APPS), reason="reference tree not present (GPU box)")
-@pytest.mark.parametrize("app", ["pagerank", "hop_dist", "triangle_counting", "sssp"])
+@pytest.mark.parametrize("app", ["pagerank", "hop_dist", "triangle_counting", "sssp", "avg_teen_cnt", "conduct"])
 def test_reference_drivers_compile_unchanged(host_built, tmp_path, app):
     """Drop-in check: the REFERENCE's own driver sources (common_main.h + <app>_main.cc), untouched and
     compiled where they lie, build and link against this repo's gm.h / generated headers / libraries."""
@@ -114,6 +114,24 @@ def test_drivers_on_golden_bin(host_built, golden):
     want = po.sssp(g, np.array(lens, np.int32), 0)[0]
     out = run_app("sssp", src, "4", "/dev/null")
     assert [int(x) for x in re.findall(r"dist\[\d\] = (\d+)", out)] == want[:10].tolist()
+    # avg_teen_cnt: every age is 10 (avg_teen_cnt_main.cc:16-18), K = 5 -> the average in-degree
+    out = run_app("avg_teen_cnt", src, "4", "/dev/null")
+    want_avg, _ = po.avg_teen_cnt(g, np.full(m["N"], 10, np.int32), 5)
+    assert re.search(r"avg = ([0-9.]+)", out).group(1) == "%0.9f" % float(want_avg)
+    # conduct: four groups from the gm_rand32 stream in vertex order (conduct_main.cc:27-38)
+    x = np.int32(np.uint32(2463534242).astype(np.int32))
+    member = []
+    for _ in range(m["N"]):
+        x = np.int32(np.uint32(x) ^ np.uint32((int(np.uint32(x)) << 13) & 0xffffffff))
+        x = np.int32(x >> 17)
+        x = np.int32(np.uint32(x) ^ np.uint32((int(np.uint32(x)) << 5) & 0xffffffff))
+        r = int(np.fmod(int(x), 100))
+        member.append(0 if r < 10 else 1 if r < 30 else 2 if r < 60 else 3)
+    want_c = 0.0
+    for i in range(4):
+        want_c += float(po.conduct(g, np.array(member, np.int32), i))
+    out = run_app("conduct", src, "4", "/dev/null")
+    assert re.search(r"sum C = ([0-9.]+)", out).group(1) == "%f" % want_c
 
 
 @pytest.mark.gpu

@@ -28,6 +28,17 @@ def test_drand48_known_values():
     assert abs(s[0] - 0.17082803610628972) < 1e-15   # well-known first drand48() value for seed 0
 
 
+def check_counts(g, c, m):
+    """avg_teen_cnt / conduct of the oracle against the reference-pinned values (floats compared by value of
+    the float32; FLT_MAX for an empty group with crossing edges cannot occur, 0 for an empty group can)."""
+    for K, want in zip((5, 25, 100), m["teen_avg_K5_K25_K100"]):
+        avg, cnt = po.avg_teen_cnt(g, c["age"], K)
+        assert np.float32(avg) == np.float32(want)
+        assert np.array_equal(cnt, c["teen_cnt"])
+    for num, want in enumerate(m["conduct_0_4"]):
+        assert np.float32(po.conduct(g, c["member"], num)) == np.float32(want)
+
+
 @pytest.mark.parametrize("name", ["rmat6_noperm", "rmat6_perm", "rmat8_noperm", "rmat8_perm",
                                   "rmat10_noperm", "rmat10_perm"])
 def test_rmat_fixture_full(golden, name):
@@ -48,6 +59,7 @@ def test_rmat_fixture_full(golden, name):
     assert np.array_equal(po.bfs_queue(g, m["root"]), c["dist"])
     assert np.array_equal(po.sssp(g, c["sssp_len"], m["root"])[0], c["sssp_dist"])
     assert sha(c["sssp_len"]) == m["sha_sssp_len"] and sha(c["sssp_dist"]) == m["sha_sssp_dist"]
+    check_counts(g, c, m)
     assert po.triangle_counting(g) == m["tc_directed"]
     assert po.triangle_counting_merge(g) == m["tc_directed"]
     gs = po.symmetrize(g)
@@ -86,6 +98,7 @@ def test_hand_graphs(golden):
         dist, _ = po.hop_dist(g, m["root"])
         assert np.array_equal(dist, c["dist"]), name
         assert np.array_equal(po.sssp(g, c["sssp_len"], m["root"])[0], c["sssp_dist"]), name
+        check_counts(g, c, m)
         assert po.triangle_counting(g) == m["tc"], name
         assert po.triangle_counting_merge(g) == m["tc"], name
 
