@@ -100,6 +100,55 @@ def test_hop_dist_full_size_properties(gmx, scale, permute):
     # (follows from the edge property; checked explicitly on the parent minima)
 
 
+def test_sssp_and_counts_full_size(gmx):
+    """SURVEY 8f rank 4 kernels at RMAT-24 through properties the host can check with numpy in seconds:
+    sssp -- dist[root] = 0, no edge is violated (dist[v] <= dist[u] + len), every reached v != root has a
+    tight in-edge; avg_teen_cnt -- teen_cnt equals a bincount over the qualifying edges, avg the emitted
+    expression; conduct -- the three integer sums recomputed on the host."""
+    scale = 24
+    N, M = 1 << scale, 16 << scale
+    g = gmx.Graph.rmat(N, M, 1997, 0.57, 0.19, 0.19, True)
+    begin, node_idx, rb, rn = g.download()
+    rng = np.random.default_rng(24)
+    length = rng.integers(1, 101, M).astype(np.int32)
+    root = int(np.argmax(np.diff(begin)))
+    dist, st = g.sssp(length, root)
+    assert dist[root] == 0 and st["iterations"] >= 2
+    src = np.repeat(np.arange(N, dtype=np.int32), np.diff(begin))
+    d64 = dist.astype(np.int64)
+    du, dv = d64[src], d64[node_idx]
+    reach_u = du != INT_MAX
+    assert np.all(dv[reach_u] <= du[reach_u] + length[reach_u])            # no violated edge
+    assert np.all(dv[~reach_u & (dv != INT_MAX)] >= 0)
+    tight = reach_u & (dv == du + length)
+    has_tight = np.zeros(N, bool)
+    has_tight[node_idx[tight]] = True
+    need = dist != INT_MAX
+    need[root] = False
+    assert np.all(has_tight[need])                                          # every distance is realised by a path
+    assert int((dist != INT_MAX).sum()) == int(g.hop_dist(root)[0].__ne__(INT_MAX).sum())   # same reachable set
+    del du, dv, tight, reach_u, d64
+
+    age = rng.integers(0, 40, N).astype(np.int32)
+    avg, cnt, _ = g.avg_teen_cnt(age, 7)
+    teen = (age >= 10) & (age < 20)
+    want_cnt = np.bincount(node_idx[teen[src]], minlength=N).astype(np.int32)
+    assert np.array_equal(cnt, want_cnt)
+    sel = age > 7
+    S = int(want_cnt[sel].astype(np.int64).sum())
+    assert S < 2 ** 31                                                     # the emitted int32 sum does not wrap here
+    assert np.float32(avg) == np.float32(float(S) / float(sel.sum()))
+
+    member = rng.integers(0, 4, N).astype(np.int32)
+    deg = np.diff(begin).astype(np.int64)
+    for num in range(4):
+        din, dout = int(deg[member == num].sum()), int(deg[member != num].sum())
+        cross = int(((member[src] == num) & (member[node_idx] != num)).sum())
+        want = np.float32(cross) / np.float32(min(din, dout))
+        assert np.float32(g.conduct(member, num)[0]) == want
+    g.free()
+
+
 def test_symmetrize_and_tc_paths_agree(gmx, golden):
     import pyoracle as po
     # device symmetrise == oracle symmetrise (small), and TC on it == reference-pinned count
