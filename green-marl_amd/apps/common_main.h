@@ -111,4 +111,41 @@ class main_t
     virtual void print_arg_info() {}
 };
 
+// This tree's own drivers are written against gm_app: the same protocol, with the three phases given as
+// callables instead of a subclass per benchmark.
+#include <functional>
+#include <string>
+#include <vector>
+
+class gm_app : public main_t
+{
+  public:
+    typedef std::function<bool(gm_graph&)> phase_fn;
+    typedef std::function<bool(const std::vector<std::string>&)> args_fn;
+
+    gm_app& usage(const char* text) { usage_ = text; return *this; }
+    gm_app& args(args_fn f) { args_ = f; return *this; }
+    gm_app& setup(phase_fn f) { setup_ = f; return *this; }
+    gm_app& kernel(phase_fn f) { kernel_ = f; return *this; }
+    gm_app& report(phase_fn f) { report_ = f; return *this; }
+    int exec(int argc, char** argv) {
+        main(argc, argv);
+        return 0;
+    }
+
+    virtual bool run() { return kernel_ ? kernel_(G) : false; }
+    virtual bool prepare() { return setup_ ? setup_(G) : true; }
+    virtual bool post_process() { return report_ ? report_(G) : true; }
+    virtual void print_arg_info() { printf("%s", usage_.c_str()); }
+    virtual bool check_args(int argc, char** argv) {
+        std::vector<std::string> v(argv, argv + argc);
+        return args_ ? args_(v) : true;
+    }
+
+  private:
+    std::string usage_;
+    args_fn args_;
+    phase_fn setup_, kernel_, report_;
+};
+
 #endif

@@ -1,29 +1,18 @@
-// triangle_counting_main.cc -- triangle counting benchmark driver; protocol and output of
-// /root/reference/apps/output_cpp/src/triangle_counting_main.cc (prints `number of triangles: %d` :19;
-// the reference narrows the int64 result to int, kept here so the checker sees the same line).
+// triangle_counting_main.cc -- triangle counting benchmark driver; output line of
+// /root/reference/apps/output_cpp/src/triangle_counting_main.cc:19 (`number of triangles: %d`: the reference
+// narrows the int64 result to int; the same line is printed so its checker sees it, plus the full count when
+// it does not fit).
 #include "common_main.h"
 #include "triangle_counting.h"
 
-class my_main : public main_t
-{
-  public:
-    int tCount;
-    int64_t tCount64;
-
-    virtual bool run() {
-        tCount64 = triangle_counting(G);
-        tCount = (int) tCount64;
-        return true;
-    }
-
-    virtual bool post_process() {
-        printf("number of triangles: %d\n", tCount);
-        if ((int64_t) tCount != tCount64) printf("number of triangles (64-bit): %lld\n", (long long) tCount64);
-        return true;
-    }
-};
-
 int main(int argc, char** argv) {
-    my_main M;
-    M.main(argc, argv);
+    int64_t triangles = 0;
+    gm_app app;
+    app.kernel([&](gm_graph& G) { triangles = triangle_counting(G); return true; })
+        .report([&](gm_graph&) {
+            printf("number of triangles: %d\n", (int) triangles);
+            if ((int64_t) (int) triangles != triangles) printf("number of triangles (64-bit): %lld\n", (long long) triangles);
+            return true;
+        });
+    return app.exec(argc, argv);
 }

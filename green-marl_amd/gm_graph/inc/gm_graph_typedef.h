@@ -11,21 +11,35 @@
 #error "libgmx is built for 32-bit node_t/edge_t (the reference default, setup.mk NODE_SIZE=32 EDGE_SIZE=32)"
 #endif
 
-typedef int32_t node_t;
-typedef int32_t edge_t;
+// ids are indices into the CSR arrays
+using node_t = int32_t;
+using edge_t = int32_t;
+
+// property value kinds, in the numbering the reference's loaders and generated code use
+enum VALUE_TYPE {
+    GMTYPE_BOOL = 0,
+    GMTYPE_INT = 1,
+    GMTYPE_LONG = 2,
+    GMTYPE_FLOAT = 3,
+    GMTYPE_DOUBLE = 4,
+    GMTYPE_NODE = 5,
+    GMTYPE_EDGE = 6,
+    GMTYPE_END = 7
+};
+
+// property column containers (names used by generated code)
+template <typename T> using gm_column = std::vector<T>;
+using GM_BVECT = gm_column<bool>;
+using GM_IVECT = gm_column<int32_t>;
+using GM_LVECT = gm_column<int64_t>;
+using GM_FVECT = gm_column<float>;
+using GM_DVECT = gm_column<double>;
+using GM_NVECT = gm_column<node_t>;
+using GM_EVECT = gm_column<edge_t>;
+
+// An application compiled for other id widths references a differently named symbol and fails to link
+// (the library defines only the 32/32 one).
 #define GM_SIZE_CHECK_VAR link_error_becuase_gm_graph_lib_is_configured_as_node32_edge32_but_the_application_is_not
-
-enum VALUE_TYPE { GMTYPE_BOOL = 0, GMTYPE_INT, GMTYPE_LONG, GMTYPE_FLOAT, GMTYPE_DOUBLE, GMTYPE_NODE, GMTYPE_EDGE, GMTYPE_END };
-
-typedef std::vector<double> GM_DVECT;
-typedef std::vector<float> GM_FVECT;
-typedef std::vector<bool> GM_BVECT;
-typedef std::vector<int64_t> GM_LVECT;
-typedef std::vector<int32_t> GM_IVECT;
-typedef std::vector<node_t> GM_NVECT;
-typedef std::vector<edge_t> GM_EVECT;
-
-// Referencing this symbol makes an application built with other id widths fail to link.
 extern int GM_SIZE_CHECK_VAR;
 static inline void gm_graph_check_node_edge_size_at_link_time() { GM_SIZE_CHECK_VAR = 0; }
 
