@@ -509,6 +509,27 @@ def test_reverse_edge_map(gmx, golden):
         assert np.all(m[1:][same] > m[:-1][same])
 
 
+@pytest.mark.parametrize("slices", [1, 2, 3, 4, 8])
+def test_pagerank_slice_counts(gmx, monkeypatch, slices):
+    """The sliced variant with every supported slice count (GMX_PR_SLICES; 3 does not divide the 8 XCDs, so the
+    static block deal is off and everything goes through the queues), fp32 and fp64, plain and in 3 chunks."""
+    monkeypatch.setenv("GMX_PR_SLICES", str(slices))
+    og = po.rmat_graph(16, permute=True)
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    want, _, want_diff = po.pagerank(og, 1e-300, 0.85, 6)
+    for elem, tol in ((4, PR_RTOL_F32), (8, PR_RTOL_F64)):
+        for chunks in (1, 3):
+            st = gmx.PageRankState(g, elem, 0, 1, gmx.GMX_PR_RELABEL | gmx.GMX_PR_HOT_LDS | gmx.GMX_PR_SLICED)
+            st.set_chunks(chunks)
+            st.reset(0.85)
+            for _ in range(6):
+                st.step()
+            assert rel_err(st.download(), want) < tol, (slices, elem, chunks)
+            assert abs(st.diff() - want_diff) <= (1e-3 if elem == 4 else 1e-9) * want_diff
+            st.free()
+    g.free()
+
+
 def test_dist_engine_world1_and_kernel_timing(gmx):
     from dist_pagerank import DistPageRank, GmxEngine
     og = po.rmat_graph(14, permute=True)
