@@ -37,7 +37,8 @@ class NumpyEngine:
         self.d = d
         self.cur = 0
         self.rank_v[:] = 1.0 / self.g.N
-        self.contrib[0].zero_()
+        # only the owned range is written (as gmx_pr_reset does): a faster peer may already have pushed its
+        # slice into this replica
         self.contrib[0][self.lo:self.hi] = torch.from_numpy(self._contrib_of(self.rank_v))
 
     def step(self):
