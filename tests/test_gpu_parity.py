@@ -404,7 +404,20 @@ def test_triangle_counting_degree_oriented_path(gmx, monkeypatch):
         plain = g.triangle_counting()[0]
         g.free()
         monkeypatch.delenv("GMX_TC_NO_ORIENT")
-        assert fast == plain == parts == po.triangle_counting(sym)
+        monkeypatch.setenv("GMX_TC_LDS", "1")
+        g = gmx.Graph.upload(sym.begin, sym.node_idx, sym.r_begin, sym.r_node_idx)
+        mem = g.triangle_counting()[0]
+        g.free()
+        monkeypatch.delenv("GMX_TC_LDS")
+        assert fast == plain == mem == parts == po.triangle_counting(sym)
+    # a clique larger than the staged-list capacity (3072): upper lists of up to 3299 entries
+    n = 3300
+    iu, ju = np.triu_indices(n, 1)
+    src = np.concatenate([iu, ju]).astype(np.int32)
+    dst = np.concatenate([ju, iu]).astype(np.int32)
+    g = gmx.Graph.from_edges(n, src, dst)
+    assert g.triangle_counting()[0] == n * (n - 1) * (n - 2) // 6
+    g.free()
     # symmetric but not simple: every edge twice, plus self-loops
     rng = np.random.default_rng(11)
     V = 300
