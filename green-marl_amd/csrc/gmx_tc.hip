@@ -157,11 +157,14 @@ tc_forward_only_kernel(const int32_t* __restrict__ begin, const int32_t* __restr
 // On the degree-ordered copy of a symmetric simple graph only the upper lists matter: Up(x) = neighbours of x
 // with a larger id (a suffix of the sorted row), and
 //     T = sum over v, over u in Up(v), of | {w in Up(v), w > u}  intersect  Up(u) |.
-// One wave per vertex v: Up(v) is staged in the wave's LDS slice once and reused for every u; for each u the
-// lanes stream Up(u) (coalesced) and binary-search the LDS copy above u's position -- or, when Up(u) is the
-// much longer list, stream the LDS tail and search Up(u) in memory.  Vertices are claimed from a counter in
-// blocks of 64, dealt to `nparts` parts round-robin for the multi-GPU form.
+// One wave per vertex v: Up(v) is staged in the wave's LDS slice once and reused for every u.  The u's are
+// taken 64 at a time, one per lane: short intersections are walked by the lane alone, long ones by the whole
+// wave (lanes stream Up(u), coalesced, and binary-search the staged tail above u's position -- or, when Up(u)
+// is the much longer list, stream the staged tail and search Up(u) in memory).  Vertices are claimed from a counter in
+// groups of 64 spread over the id range; the multi-GPU form deals the vertices to `nparts` parts round-robin.
 #define TCO_WAVES 4
+#define TCO_CLAIM 8     // work items per dequeue
+#define TCO_ALONE 24    // a lane walks a side of up to this many entries by itself
 #define TCO_CAP 3072    // upper-list entries staged per wave (12 KiB; 4 waves: 48 KiB of LDS per workgroup)
 
 __global__ void tc_up_begin_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx, int64_t V,
@@ -179,52 +182,98 @@ __device__ __forceinline__ int32_t tco_lds_lower_bound(const int32_t* a, int32_t
     return lo;
 }
 
+// groups of 64 slots per vertex (a vertex with da upper neighbours has da - 1 slots that can close a triangle)
+__global__ void tc_groups_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ up_begin, int64_t V,
+                                 int32_t* __restrict__ groups) {
+    int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; v < V; v += stride) {
+        const int32_t da = begin[v + 1] - up_begin[v];
+        groups[v] = da >= 2 ? (da - 1 + 63) / 64 : 0;
+    }
+}
+
+// Work item = (vertex v, group g of 64 of its slots): a hub-like vertex (thousands of upper neighbours, each
+// with thousands of its own) is spread over many waves.  grp_off[V+1] = exclusive scan of the group counts.
 __global__ void __launch_bounds__(TCO_WAVES * 64)
 tc_oriented_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx, const int32_t* __restrict__ up_begin,
-                   int64_t V, int part, int nparts, unsigned long long* __restrict__ next_block,
-                   unsigned long long* __restrict__ total) {
+                   const int32_t* __restrict__ grp_off, int64_t V, int part, int nparts,
+                   unsigned long long* __restrict__ next_claim, unsigned long long* __restrict__ total) {
     __shared__ int32_t s_up[TCO_WAVES][TCO_CAP];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     int32_t* A = s_up[wv];
-    const int64_t nblocks = (V + 63) / 64;
-    const int64_t my_blocks = (nblocks - part + nparts - 1) / nparts;   // blocks part, part + nparts, ...
+    const int64_t G = grp_off[V];
+    const int64_t Q = G > part ? (G - part + nparts - 1) / nparts : 0;   // items part, part + nparts, ...
     unsigned long long c = 0;
     for (;;) {
         unsigned long long b = 0;
-        if (lane == 0) b = atomicAdd(next_block, 1ULL);
+        if (lane == 0) b = atomicAdd(next_claim, (unsigned long long) TCO_CLAIM);
         b = __shfl(b, 0, 64);
-        if ((int64_t) b >= my_blocks) break;
-        const int64_t v0 = ((int64_t) b * nparts + part) * 64;
-        for (int64_t v = v0; v < v0 + 64 && v < V; v++) {
-            const int32_t ab = up_begin[v], ae = begin[v + 1];
-            const int32_t da = ae - ab;
-            if (da < 2) continue;                       // a triangle needs two upper neighbours
+        if ((int64_t) b >= Q) break;
+        int64_t v = -1;
+        for (int64_t q = (int64_t) b; q < (int64_t) b + TCO_CLAIM && q < Q; q++) {
+            const int64_t item = q * nparts + part;
+            if (v < 0 || (int64_t) grp_off[v + 1] <= item) {   // vertex of the item: last v with grp_off[v] <= item
+                int64_t lo = 0, hi = V;
+                while (hi - lo > 1) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if ((int64_t) grp_off[mid] <= item) lo = mid; else hi = mid;
+                }
+                v = lo;
+            }
+            const int32_t base = (int32_t) (item - grp_off[v]) * 64;   // first slot of the group
+            const int32_t ab = up_begin[v] + base, ae = begin[v + 1];
+            const int32_t da = ae - ab;                                  // Up(v) from the group's first slot on
             const bool in_lds = da <= TCO_CAP;
             if (in_lds) {
-                for (int32_t j = lane; j < da; j += 64) A[j] = node_idx[ab + j];
+                for (int32_t k = lane; k < da; k += 64) A[k] = node_idx[ab + k];
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_s_waitcnt(0xc07f);     // the wave's own LDS writes are visible to all its lanes
                 __builtin_amdgcn_wave_barrier();
             }
-            for (int32_t i = 0; i + 1 < da; i++) {
+            // one slot per lane.  A lane whose shorter side is short walks it alone (probing the staged list or
+            // Up(u)); the others are taken one after the other by the whole wave, lanes striding over the side
+            // that is cheaper to stream.
+            const int32_t i = lane;
+            const bool act = i + 1 < da;
+            int32_t bb = 0, be = 0;
+            if (act) {
                 const int32_t u = in_lds ? A[i] : node_idx[ab + i];
-                const int32_t bb = up_begin[u], be = begin[u + 1];
-                const int32_t db = be - bb, ta = da - (i + 1);
-                if (db == 0) continue;
-                if (in_lds && db <= 8 * ta) {
-                    // stream Up(u), search the staged tail A[i+1 .. da)
-                    for (int32_t j = bb + lane; j < be; j += 64) {
-                        const int32_t w = node_idx[j];
-                        const int32_t p = tco_lds_lower_bound(A, i + 1, da, w);
-                        c += (p < da && A[p] == w) ? 1 : 0;
+                bb = up_begin[u];
+                be = begin[u + 1];
+            }
+            const int32_t db = be - bb, ta = act ? da - (i + 1) : 0;
+            const int32_t shorter = db < ta ? db : ta;
+            if (act && shorter > 0 && shorter <= TCO_ALONE) {
+                if (db <= ta) {
+                    for (int32_t p = bb; p < be; p++) {
+                        const int32_t w = node_idx[p];
+                        if (in_lds) {
+                            const int32_t f = tco_lds_lower_bound(A, i + 1, da, w);
+                            c += (f < da && A[f] == w) ? 1 : 0;
+                        } else c += tc_contains(node_idx, ab + i + 1, ae, w) ? 1 : 0;
                     }
                 } else {
-                    // stream the tail of Up(v), search Up(u) in memory
-                    for (int32_t j = i + 1 + lane; j < da; j += 64) {
-                        const int32_t w = in_lds ? A[j] : node_idx[ab + j];
-                        c += tc_contains(node_idx, bb, be, w) ? 1 : 0;
+                    for (int32_t p = i + 1; p < da; p++)
+                        c += tc_contains(node_idx, bb, be, in_lds ? A[p] : node_idx[ab + p]) ? 1 : 0;
+                }
+            }
+            unsigned long long m = __ballot(act && shorter > TCO_ALONE);
+            while (m) {
+                const int src = __ffsll((long long) m) - 1;
+                m &= m - 1;
+                const int32_t sbb = __shfl(bb, src, 64), sbe = __shfl(be, src, 64);
+                const int32_t sdb = sbe - sbb, sta = da - (src + 1);
+                if (in_lds && sdb <= 8 * sta) {       // stream Up(u), search the staged tail
+                    for (int32_t p = sbb + lane; p < sbe; p += 64) {
+                        const int32_t w = node_idx[p];
+                        const int32_t f = tco_lds_lower_bound(A, src + 1, da, w);
+                        c += (f < da && A[f] == w) ? 1 : 0;
                     }
+                } else {                               // stream the tail of Up(v), search Up(u) in memory
+                    for (int32_t p = src + 1 + lane; p < da; p += 64)
+                        c += tc_contains(node_idx, sbb, sbe, in_lds ? A[p] : node_idx[ab + p]) ? 1 : 0;
                 }
             }
             __builtin_amdgcn_wave_barrier();            // all lanes are done with A before it is overwritten
@@ -235,9 +284,10 @@ tc_oriented_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict_
     if (lane == 0 && c) atomicAdd(total, c);
 }
 
-// The staged-list kernel is opt-in (GMX_TC_LDS=1) until it beats the slot kernels: first version 1.8 s against
-// 0.59 s on RMAT-24 symmetrised -- one wave per vertex walks the u's one after the other, and most upper lists
-// are far shorter than a wave.
+// The staged-list kernel is opt-in (GMX_TC_LDS=1): on RMAT-24 symmetrised it takes 604 ms against 585 ms for the
+// slot kernels that search both lists in memory (first versions: 1.8 s with one wave walking a whole vertex,
+// 580 ms with vertices interleaved over the waves, 604 ms with 64-slot work items) -- no gain yet, kept as the
+// starting point for the LDS formulation BASELINE.json's config names.
 static bool tc_use_lds() {
     const char* e = getenv("GMX_TC_LDS");
     return e && atoi(e) != 0 && !getenv("GMX_TC_NO_LDS");
@@ -334,6 +384,23 @@ static int tc_counting_graph(gmx_graph* g, gmx_graph** out, bool* oriented) {
                 return st;
             }
             hipLaunchKernelGGL(tc_up_begin_kernel, dim3(tc_grid(g->V)), dim3(TC_THREADS), 0, s, o->begin.p, o->node_idx.p, g->V, o->r_begin.p);
+            // work items of the staged-list kernel: exclusive scan of the 64-slot groups per vertex (kept in the
+            // copy's otherwise unused r_node_idx)
+            {
+                dbuf<int32_t> groups;
+                if ((st = groups.alloc((size_t) g->V + 1)) || (st = o->r_node_idx.alloc((size_t) g->V + 1))) {
+                    delete o;
+                    return st;
+                }
+                GMX_HIP(hipMemsetAsync(groups.p + g->V, 0, sizeof(int32_t), s));
+                hipLaunchKernelGGL(tc_groups_kernel, dim3(tc_grid(g->V)), dim3(TC_THREADS), 0, s, o->begin.p, (const int32_t*) o->r_begin.p, g->V, groups.p);
+                size_t tb2 = 0;
+                GMX_HIP(rocprim::exclusive_scan(nullptr, tb2, groups.p, o->r_node_idx.p, 0, (size_t) g->V + 1, rocprim::plus<int32_t>(), s));
+                dbuf<char> tmp2;
+                GMX_CHECK(tmp2.alloc(tb2));
+                GMX_HIP(rocprim::exclusive_scan((void*) tmp2.p, tb2, groups.p, o->r_node_idx.p, 0, (size_t) g->V + 1, rocprim::plus<int32_t>(), s));
+                GMX_HIP(hipStreamSynchronize(s));
+            }
             GMX_HIP(hipStreamSynchronize(s));
             g->tc_oriented = o;
         }
@@ -376,8 +443,8 @@ extern "C" int gmx_triangle_counting_part(gmx_graph_t* g, int part, int nparts, 
     GMX_HIP(hipEventRecord(ev0, 0));
     int64_t blocks = (nlocal + TC_THREADS - 1) / TC_THREADS;
     if (oriented && tc_use_lds()) {
-        hipLaunchKernelGGL(tc_oriented_kernel, dim3(256 * 4), dim3(TCO_WAVES * 64), 0, 0, g->begin.p, g->node_idx.p,
-                           (const int32_t*) g->r_begin.p, g->V, part, nparts, ctr.p + 1, ctr.p);
+        hipLaunchKernelGGL(tc_oriented_kernel, dim3(256 * 3), dim3(TCO_WAVES * 64), 0, 0, g->begin.p, g->node_idx.p,
+                           (const int32_t*) g->r_begin.p, (const int32_t*) g->r_node_idx.p, g->V, part, nparts, ctr.p + 1, ctr.p);
         GMX_HIP(hipGetLastError());
     } else if (g->has_reverse || oriented) {
         dbuf<tc_pair> big;
