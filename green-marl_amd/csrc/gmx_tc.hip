@@ -164,8 +164,9 @@ tc_forward_only_kernel(const int32_t* __restrict__ begin, const int32_t* __restr
 // groups of 64 spread over the id range; the multi-GPU form deals the vertices to `nparts` parts round-robin.
 #define TCO_WAVES 4
 #define TCO_CLAIM 8     // work items per dequeue
-#define TCO_ALONE 24    // a lane walks a side of up to this many entries by itself
-#define TCO_CAP 3072    // upper-list entries staged per wave (12 KiB; 4 waves: 48 KiB of LDS per workgroup)
+#define TCO_ALONE 4     // a lane walks a side of up to this many entries by itself (measured flat from 0 to 8; 48: +25 %)
+#define TCO_RATIO 4     // stream Up(u) and search the staged tail while |Up(u)| <= TCO_RATIO * |tail| (2: +15 %, 16: +7 %)
+#define TCO_CAP 1024    // upper-list entries staged per wave (4 KiB; 4 waves: 16 KiB of LDS per workgroup, 8 workgroups per CU)
 
 __global__ void tc_up_begin_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx, int64_t V,
                                    int32_t* __restrict__ up_begin) {
@@ -197,7 +198,7 @@ __global__ void tc_groups_kernel(const int32_t* __restrict__ begin, const int32_
 // with thousands of its own) is spread over many waves.  grp_off[V+1] = exclusive scan of the group counts.
 __global__ void __launch_bounds__(TCO_WAVES * 64)
 tc_oriented_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx, const int32_t* __restrict__ up_begin,
-                   const int32_t* __restrict__ grp_off, int64_t V, int part, int nparts,
+                   const int32_t* __restrict__ grp_off, int64_t V, int part, int nparts, int alone_max, int ratio,
                    unsigned long long* __restrict__ next_claim, unsigned long long* __restrict__ total) {
     __shared__ int32_t s_up[TCO_WAVES][TCO_CAP];
     const int lane = threadIdx.x & 63;
@@ -245,7 +246,7 @@ tc_oriented_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict_
             }
             const int32_t db = be - bb, ta = act ? da - (i + 1) : 0;
             const int32_t shorter = db < ta ? db : ta;
-            if (act && shorter > 0 && shorter <= TCO_ALONE) {
+            if (act && shorter > 0 && shorter <= alone_max) {
                 if (db <= ta) {
                     for (int32_t p = bb; p < be; p++) {
                         const int32_t w = node_idx[p];
@@ -259,13 +260,13 @@ tc_oriented_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict_
                         c += tc_contains(node_idx, bb, be, in_lds ? A[p] : node_idx[ab + p]) ? 1 : 0;
                 }
             }
-            unsigned long long m = __ballot(act && shorter > TCO_ALONE);
+            unsigned long long m = __ballot(act && shorter > alone_max);
             while (m) {
                 const int src = __ffsll((long long) m) - 1;
                 m &= m - 1;
                 const int32_t sbb = __shfl(bb, src, 64), sbe = __shfl(be, src, 64);
                 const int32_t sdb = sbe - sbb, sta = da - (src + 1);
-                if (in_lds && sdb <= 8 * sta) {       // stream Up(u), search the staged tail
+                if (in_lds && sdb <= ratio * sta) {   // stream Up(u), search the staged tail
                     for (int32_t p = sbb + lane; p < sbe; p += 64) {
                         const int32_t w = node_idx[p];
                         const int32_t f = tco_lds_lower_bound(A, src + 1, da, w);
@@ -284,14 +285,12 @@ tc_oriented_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict_
     if (lane == 0 && c) atomicAdd(total, c);
 }
 
-// The staged-list kernel is opt-in (GMX_TC_LDS=1): on RMAT-24 symmetrised it takes 604 ms against 585 ms for the
-// slot kernels that search both lists in memory (first versions: 1.8 s with one wave walking a whole vertex,
-// 580 ms with vertices interleaved over the waves, 604 ms with 64-slot work items) -- no gain yet, kept as the
-// starting point for the LDS formulation BASELINE.json's config names.
-static bool tc_use_lds() {
-    const char* e = getenv("GMX_TC_LDS");
-    return e && atoi(e) != 0 && !getenv("GMX_TC_NO_LDS");
-}
+// The staged-list kernel is the default on the degree-ordered copy (GMX_TC_NO_LDS=1 selects the slot kernels that
+// search both lists in memory).  RMAT-24 symmetrised: 282 ms against 585 ms.  Its history is a lesson in
+// occupancy: 1.8 s with one wave walking a whole vertex, 580 ms with vertices interleaved over the waves,
+// 604 ms with 64-slot work items and 12 KiB of LDS per wave (12 waves per CU), 298 ms with 4 KiB per wave
+// (32 waves per CU; lists over 1024 entries are searched in memory), 282 ms after tuning the two thresholds.
+static bool tc_use_lds() { return !getenv("GMX_TC_NO_LDS"); }
 
 // ------------------------------------------------------------------ degree-oriented copy
 static int tc_grid(int64_t n) {
@@ -443,8 +442,9 @@ extern "C" int gmx_triangle_counting_part(gmx_graph_t* g, int part, int nparts, 
     GMX_HIP(hipEventRecord(ev0, 0));
     int64_t blocks = (nlocal + TC_THREADS - 1) / TC_THREADS;
     if (oriented && tc_use_lds()) {
-        hipLaunchKernelGGL(tc_oriented_kernel, dim3(256 * 3), dim3(TCO_WAVES * 64), 0, 0, g->begin.p, g->node_idx.p,
-                           (const int32_t*) g->r_begin.p, (const int32_t*) g->r_node_idx.p, g->V, part, nparts, ctr.p + 1, ctr.p);
+        hipLaunchKernelGGL(tc_oriented_kernel, dim3(256 * 8), dim3(TCO_WAVES * 64), 0, 0, g->begin.p, g->node_idx.p,
+                           (const int32_t*) g->r_begin.p, (const int32_t*) g->r_node_idx.p, g->V, part, nparts,
+                           TCO_ALONE, TCO_RATIO, ctr.p + 1, ctr.p);
         GMX_HIP(hipGetLastError());
     } else if (g->has_reverse || oriented) {
         dbuf<tc_pair> big;

@@ -194,13 +194,13 @@ def test_triangle_counting_rmat24_symmetrized_runs(gmx, monkeypatch):
     monkeypatch.setenv("GMX_TC_NO_ORIENT", "1")
     T_emitted, st_e = gs.triangle_counting()
     monkeypatch.delenv("GMX_TC_NO_ORIENT")
-    monkeypatch.setenv("GMX_TC_LDS", "1")             # degree order with the upper list staged in LDS (opt-in)
+    monkeypatch.setenv("GMX_TC_NO_LDS", "1")          # degree order, both lists searched in memory (the slot kernels)
     T_mem, st_m = gs.triangle_counting()
-    monkeypatch.delenv("GMX_TC_LDS")
+    monkeypatch.delenv("GMX_TC_NO_LDS")
     assert T == T_emitted == T_mem
     assert sum(gs.triangle_counting(p, 3)[0] for p in range(3)) == T
-    print("emitted order: %.1f ms; degree order: %.1f ms (%.1f ms cached); degree order, list staged in LDS: %.1f ms"
-          % (st_e["kernel_ms"], st["kernel_ms"], st2["kernel_ms"], st_m["kernel_ms"]))
+    print("emitted order: %.1f ms; degree order, lists searched in memory: %.1f ms; degree order, list staged in LDS (default): %.1f ms (%.1f ms cached)"
+          % (st_e["kernel_ms"], st_m["kernel_ms"], st["kernel_ms"], st2["kernel_ms"]))
     # a triangle {a<b<c} of a simple undirected graph is counted exactly once by the emitted rule, so
     # T is bounded by sum_v C(d(v),2)/... ; sanity: T <= E * max_degree
     b = gs.download(reverse=False)[0]

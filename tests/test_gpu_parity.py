@@ -404,11 +404,11 @@ def test_triangle_counting_degree_oriented_path(gmx, monkeypatch):
         plain = g.triangle_counting()[0]
         g.free()
         monkeypatch.delenv("GMX_TC_NO_ORIENT")
-        monkeypatch.setenv("GMX_TC_LDS", "1")
+        monkeypatch.setenv("GMX_TC_NO_LDS", "1")
         g = gmx.Graph.upload(sym.begin, sym.node_idx, sym.r_begin, sym.r_node_idx)
         mem = g.triangle_counting()[0]
         g.free()
-        monkeypatch.delenv("GMX_TC_LDS")
+        monkeypatch.delenv("GMX_TC_NO_LDS")
         assert fast == plain == mem == parts == po.triangle_counting(sym)
     # a clique larger than the staged-list capacity (3072): upper lists of up to 3299 entries
     n = 3300
