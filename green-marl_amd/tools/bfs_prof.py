@@ -19,21 +19,6 @@ for scale in scales:
             scale, perm, root, s["kernel_ms"], s["iterations"], s["vertices_reached"], s["edges_examined"], s["edges_reached"],
             s["edges_reached"] / s["kernel_ms"] / 1e6,
             (8 * s["edges_reached"] + 12 * s["vertices_reached"]) / s["kernel_ms"] / 1e6), flush=True)
-        # the stepping object (gmx_bfs_*): whole traversal on one rank, and rank 0's share of an 8-rank partition
-        for nranks in (1, 8):
-            st = gmx.BfsState(g, 0, nranks)
-            for rep in range(2):
-                st.start(root)
-                t0 = time.perf_counter()
-                lv = bu = 0
-                while True:
-                    bu += 1 if st.step_begin() or nranks == 1 and False else 0
-                    if st.step_end() == 0:
-                        break
-                    lv += 1
-                dt = (time.perf_counter() - t0) * 1e3
-            print("   stepping object nranks=%d (rank 0, no exchange): %.3f ms wall, %d levels, %d partitioned" % (nranks, dt, lv, bu), flush=True)
-            st.free()
         if do_tc and perm == 0:
             t0 = time.time()
             T, s = g.triangle_counting()
