@@ -198,11 +198,11 @@ struct gmx_bfs {
 __global__ void __launch_bounds__(BFS_THREADS)
 bfs_bottomup_part_kernel(const int32_t* __restrict__ r_begin, const int32_t* __restrict__ r_node_idx,
                          int64_t v_lo, int64_t v_hi, int64_t V, const uint32_t* __restrict__ frontier_bm,
-                         const int32_t* __restrict__ dist, unsigned long long* __restrict__ found_bm,
-                         bfs_counters* __restrict__ ctr) {
+                         const int32_t* dist, unsigned long long* __restrict__ found_bm,
+                         int32_t* dist_w /* NULL or == dist */, int32_t next_level, bfs_counters* __restrict__ ctr) {
     int64_t t = v_lo + (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
-    unsigned long long inspected = 0;
+    unsigned long long inspected = 0, found_cnt = 0;
     for (; t < v_hi; t += stride) {   // v_hi - v_lo is a multiple of 64: whole waves
         bool found = false;
         if (t < V && dist[t] == INT_MAX) {
@@ -218,10 +218,19 @@ bfs_bottomup_part_kernel(const int32_t* __restrict__ r_begin, const int32_t* __r
         }
         const unsigned long long m = __ballot(found);
         if ((threadIdx.x & 63) == 0) found_bm[t >> 6] = m;
+        // single rank: the whole bitmap is this rank's, so dist[] can be settled right here (dist_w aliases dist;
+        // a vertex only ever reads its own entry) and the separate apply pass is not needed
+        if (dist_w) {
+            if (found) dist_w[t] = next_level;
+            if ((threadIdx.x & 63) == 0) found_cnt += (unsigned long long) __popcll(m);
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) inspected += __shfl_down(inspected, off, 64);
-    if ((threadIdx.x & 63) == 0 && inspected) atomicAdd(&ctr->edges, inspected);
+    if ((threadIdx.x & 63) == 0) {
+        if (inspected) atomicAdd(&ctr->edges, inspected);
+        if (found_cnt) atomicAdd(&ctr->next_count, found_cnt);
+    }
 }
 
 // every rank, whole bitmap: dist[v] = next_level where the bit is set; counts the new frontier
@@ -332,7 +341,7 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
         const int64_t v_hi = v_lo + b->slice_words * 64;
         hipLaunchKernelGGL(bfs_bottomup_part_kernel, dim3(grid_for(v_hi - v_lo, BFS_THREADS, 256 * 32)), dim3(BFS_THREADS), 0, 0,
                            g->r_begin.p, g->r_node_idx.p, v_lo, v_hi, V, (const uint32_t*) b->bm[b->fr].p,
-                           (const int32_t*) b->dist.p, b->bm[1 - b->fr].p, b->ctr.p);
+                           (const int32_t*) b->dist.p, b->bm[1 - b->fr].p, b->nranks == 1 ? b->dist.p : nullptr, b->level + 1, b->ctr.p);
         b->pending_bottom_up = true;
         *needs_exchange = b->nranks > 1 ? 1 : 0;
     } else {
@@ -371,9 +380,11 @@ extern "C" int gmx_bfs_step_end(gmx_bfs_t* b, int64_t* next_count) {
     *next_count = 0;
     if (b->cur_count <= 0) return GMX_OK;
     if (b->pending_bottom_up) {
-        hipLaunchKernelGGL(bfs_apply_found_kernel, dim3(grid_for(b->V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
-                           (const unsigned long long*) b->bm[1 - b->fr].p, b->V, b->level + 1, b->dist.p, b->ctr.p);
-        GMX_HIP(hipGetLastError());
+        if (b->nranks > 1) {   // (a single rank has settled dist[] and the count inside the bottom-up kernel)
+            hipLaunchKernelGGL(bfs_apply_found_kernel, dim3(grid_for(b->V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
+                               (const unsigned long long*) b->bm[1 - b->fr].p, b->V, b->level + 1, b->dist.p, b->ctr.p);
+            GMX_HIP(hipGetLastError());
+        }
         b->fr = 1 - b->fr;   // what was found is the next frontier
         b->frontier_is_bitmap = b->frontier_bm_valid = true;
         b->pending_bottom_up = false;
