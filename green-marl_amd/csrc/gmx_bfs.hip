@@ -146,6 +146,25 @@ __global__ void bfs_level_queue_kernel(const int32_t* __restrict__ dist, int64_t
     }
 }
 
+// queue of the vertices whose bit is set (the frontier a bottom-up level left behind): 8 bytes per 64 vertices
+// to read instead of their dist[] entries
+__global__ void bfs_bitmap_queue_kernel(const unsigned long long* __restrict__ bm64, int64_t V,
+                                        int32_t* __restrict__ q, unsigned long long* __restrict__ qcount) {
+    int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    const int64_t vend = (V + 63) / 64 * 64;
+    for (; v < vend; v += stride) {
+        const unsigned long long m = bm64[v >> 6];      // one word per wave (v is lane-aligned)
+        if (m) {
+            const int lane = threadIdx.x & 63;
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(qcount, (unsigned long long) __popcll(m));
+            base = __shfl(base, 0, 64);
+            if ((m >> lane) & 1ULL) q[base + __popcll(m & ((1ULL << lane) - 1))] = (int32_t) v;
+        }
+    }
+}
+
 // out-edges of the reached vertices (what Graph500 divides by the traversal time)
 __global__ void bfs_edges_reached_kernel(const int32_t* __restrict__ dist, const int32_t* __restrict__ begin, int64_t V,
                                          unsigned long long* __restrict__ out) {
@@ -192,6 +211,14 @@ struct gmx_bfs {
     bool frontier_is_bitmap = false, frontier_bm_valid = false, pending_bottom_up = false;
     int32_t* cur_q = nullptr;
     int32_t* next_q = nullptr;
+    // per-level read-backs (frontier size, frontier edges) go through pinned host memory: a level costs two
+    // host round trips, and with pageable memory each is a staged copy -- at RMAT-24 that was most of the time
+    bfs_counters* h_ctr = nullptr;
+    int64_t* h_mf = nullptr;
+    ~gmx_bfs() {
+        if (h_ctr) (void) hipHostFree(h_ctr);
+        if (h_mf) (void) hipHostFree(h_mf);
+    }
 };
 
 // owned vertices [v_lo, v_hi), v_lo a multiple of 64: one found word per wave, no atomics
@@ -271,6 +298,12 @@ extern "C" int gmx_bfs_create(gmx_graph_t* g, int rank, int nranks, gmx_bfs_t** 
         delete b;
         return st;
     }
+    if (hipHostMalloc((void**) &b->h_ctr, sizeof(bfs_counters), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**) &b->h_mf, sizeof(int64_t), hipHostMallocDefault) != hipSuccess) {
+        delete b;
+        gmx_set_error("bfs: pinned host allocation failed");
+        return GMX_ERR_HIP;
+    }
     if (rocprim::inclusive_scan(nullptr, b->scan_bytes, b->deg.p, b->off.p + 1, V1, rocprim::plus<int64_t>(), 0) != hipSuccess ||
         (st = b->scan_tmp.alloc(b->scan_bytes))) {
         delete b;
@@ -291,6 +324,7 @@ extern "C" int gmx_bfs_start(gmx_bfs_t* b, gmx_node_t root) {
     const int64_t V = b->V;
     const bool root_ok = root >= 0 && root < V;
     if (V > 0) hipLaunchKernelGGL(bfs_init_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, b->dist.p, V, root_ok ? root : -1);
+    GMX_HIP(hipMemset(b->ctr.p, 0, sizeof(bfs_counters)));
     GMX_HIP(hipMemset(b->bm[0].p, 0, sizeof(unsigned long long) * (size_t) b->words));
     GMX_HIP(hipMemset(b->bm[1].p, 0, sizeof(unsigned long long) * (size_t) b->words));
     b->level = 0;
@@ -312,7 +346,9 @@ static int bfs_frontier_edges(gmx_bfs* b, int64_t* m_f) {
     size_t tb = b->scan_bytes;
     GMX_HIP(rocprim::inclusive_scan(b->scan_tmp.p, tb, b->deg.p, b->off.p + 1, (size_t) b->cur_count, rocprim::plus<int64_t>(), 0));
     GMX_HIP(hipMemsetAsync(b->off.p, 0, sizeof(int64_t), 0));
-    GMX_HIP(hipMemcpy(m_f, b->off.p + b->cur_count, sizeof(int64_t), hipMemcpyDeviceToHost));
+    GMX_HIP(hipMemcpyAsync(b->h_mf, b->off.p + b->cur_count, sizeof(int64_t), hipMemcpyDeviceToHost, 0));
+    GMX_HIP(hipStreamSynchronize(0));
+    *m_f = *b->h_mf;
     return GMX_OK;
 }
 
@@ -323,8 +359,7 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
     if (b->cur_count <= 0) return GMX_OK;
     gmx_graph* g = b->g;
     const int64_t V = b->V;
-    bfs_counters zero = {0, b->edges};
-    GMX_HIP(hipMemcpy(b->ctr.p, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    GMX_HIP(hipMemsetAsync(&b->ctr.p->next_count, 0, sizeof(unsigned long long), 0));   // `edges` keeps accumulating
     int64_t m_f = 0;
     bool bottom_up;
     if (b->frontier_is_bitmap) bottom_up = b->cur_count > V / 24;
@@ -347,8 +382,12 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
     } else {
         if (b->frontier_is_bitmap) {   // back from bottom-up: rebuild the queue and its edge offsets
             GMX_HIP(hipMemsetAsync(b->qcount.p, 0, sizeof(unsigned long long), 0));
-            hipLaunchKernelGGL(bfs_level_queue_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
-                               (const int32_t*) b->dist.p, V, b->level, b->cur_q, b->qcount.p);
+            if (b->frontier_bm_valid)   // the frontier is the bitmap the last bottom-up level found
+                hipLaunchKernelGGL(bfs_bitmap_queue_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
+                                   (const unsigned long long*) b->bm[b->fr].p, V, b->cur_q, b->qcount.p);
+            else
+                hipLaunchKernelGGL(bfs_level_queue_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
+                                   (const int32_t*) b->dist.p, V, b->level, b->cur_q, b->qcount.p);
             b->frontier_is_bitmap = false;
             GMX_CHECK(bfs_frontier_edges(b, &m_f));
             b->explored += m_f;
@@ -389,8 +428,9 @@ extern "C" int gmx_bfs_step_end(gmx_bfs_t* b, int64_t* next_count) {
         b->frontier_is_bitmap = b->frontier_bm_valid = true;
         b->pending_bottom_up = false;
     }
-    bfs_counters h;
-    GMX_HIP(hipMemcpy(&h, b->ctr.p, sizeof(h), hipMemcpyDeviceToHost));
+    GMX_HIP(hipMemcpyAsync(b->h_ctr, b->ctr.p, sizeof(bfs_counters), hipMemcpyDeviceToHost, 0));
+    GMX_HIP(hipStreamSynchronize(0));
+    const bfs_counters h = *b->h_ctr;
     b->cur_count = (int64_t) h.next_count;
     b->edges = h.edges;
     b->reached += b->cur_count;
