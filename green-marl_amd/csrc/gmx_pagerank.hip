@@ -124,6 +124,7 @@ struct gmx_pr {
     std::vector<hipStream_t> push_stream;    // [nranks]
     std::vector<hipEvent_t> push_done;       // [nranks]
     hipEvent_t push_ready = nullptr;         // "this chunk is computed", recorded on the step's stream
+    double* h_diff = nullptr;                // pinned landing place of gmx_pr_diff
     // dominant-kernel timing (hipEvents on the launch stream)
     bool timing = false;
     std::vector<hipEvent_t> ev;   // pairs
@@ -138,6 +139,7 @@ struct gmx_pr {
         for (hipEvent_t e : push_done)
             if (e) (void) hipEventDestroy(e);
         if (push_ready) (void) hipEventDestroy(push_ready);
+        if (h_diff) (void) hipHostFree(h_diff);
     }
 };
 
@@ -1737,8 +1739,12 @@ extern "C" int gmx_pr_diff_ptr(gmx_pr_t* p, void** dev_ptr) {
 
 extern "C" int gmx_pr_diff(gmx_pr_t* p, void* stream, double* diff) {
     GMX_REQUIRE(p && diff, "NULL argument");
-    GMX_HIP(hipMemcpyAsync(diff, p->diff.p, sizeof(double), hipMemcpyDeviceToHost, (hipStream_t) stream));
+    // the emitted loop reads diff every iteration: through pinned memory, so the read-back is one small DMA and
+    // not a staged pageable copy
+    if (!p->h_diff) GMX_HIP(hipHostMalloc((void**) &p->h_diff, sizeof(double), hipHostMallocDefault));
+    GMX_HIP(hipMemcpyAsync(p->h_diff, p->diff.p, sizeof(double), hipMemcpyDeviceToHost, (hipStream_t) stream));
     GMX_HIP(hipStreamSynchronize((hipStream_t) stream));
+    *diff = *p->h_diff;
     return GMX_OK;
 }
 
