@@ -456,8 +456,8 @@ extern "C" int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host,
     GMX_REQUIRE(g && dist_host, "NULL argument");
     if (stats) memset(stats, 0, sizeof(*stats));
     if (g->V == 0) return GMX_OK;
-    gmx_bfs_t* b = nullptr;
-    GMX_CHECK(gmx_bfs_create(g, 0, 1, &b));
+    if (!g->bfs_cache) GMX_CHECK(gmx_bfs_create(g, 0, 1, &g->bfs_cache));   // graph preprocessing, like the reverse CSR
+    gmx_bfs_t* b = g->bfs_cache;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     for (hipEvent_t& e : ev) (void) hipEventCreate(&e);
     int st = GMX_OK;
@@ -495,7 +495,6 @@ extern "C" int gmx_hop_dist(gmx_graph_t* g, gmx_node_t root, int32_t* dist_host,
     }
     for (hipEvent_t e : ev)
         if (e) (void) hipEventDestroy(e);
-    gmx_bfs_free(b);
     return st;
 }
 

@@ -557,6 +557,8 @@ extern "C" int gmx_graph_free(gmx_graph_t* g) {
         }
         delete g->tc_oriented;
         g->tc_oriented = nullptr;
+        if (g->bfs_cache) gmx_bfs_free(g->bfs_cache);
+        g->bfs_cache = nullptr;
     }
     delete g;
     return GMX_OK;

@@ -67,6 +67,8 @@ struct dbuf {
     T* take() { T* q = p; p = nullptr; n = 0; return q; }
 };
 
+struct gmx_bfs;
+
 struct gmx_graph {
     int64_t V = 0, E = 0;
     bool has_reverse = false;
@@ -80,6 +82,9 @@ struct gmx_graph {
     // forward CSR of the same graph renumbered by ascending degree (its reverse CSR is the same arrays)
     int tc_sym_state = -1;
     gmx_graph* tc_oriented = nullptr;
+    // hop_dist: the single-rank traversal state (queues, bitmaps, dist[]) of the whole-kernel entry, kept for the
+    // next call on the same graph instead of nine allocations per call
+    gmx_bfs* bfs_cache = nullptr;
 };
 
 // ---- graph construction helpers (gmx_graph.hip) ----
