@@ -613,6 +613,54 @@ def test_edge_case_duplicate_edges_and_self_loops(gmx):
     _check_all_kernels(gmx, og, root=1)
 
 
+@pytest.mark.parametrize("V,E,nranks,chunks", [(100003, 1200007, 1, 1), (100003, 1200007, 3, 2), (65537, 300000, 5, 2),
+                                               (4099, 20000, 2, 3), (1, 0, 1, 1), (3, 5, 2, 2)])
+def test_pagerank_odd_sizes_all_variants(gmx, V, E, nranks, chunks):
+    """Vertex and edge counts that are not multiples of anything (prime V, ranges padded to whole slice runs,
+    a short last rank, ranks owning no row at all), every kernel variant, N ranks side by side with the sweep
+    in row chunks where the variant supports it."""
+    import torch
+    rng = np.random.default_rng(V + E)
+    src = (rng.zipf(1.4, E) % max(V, 1)).astype(np.int32) if E else np.zeros(0, np.int32)   # skewed out-degrees
+    dst = rng.integers(0, max(V, 1), E).astype(np.int32)
+    og = po.graph_from_edges(V, src, dst)
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    iters = 6
+    want, _, want_diff = po.pagerank(og, 1e-300, 0.85, iters)
+    for options in (1, 3, 7):
+        states = [gmx.PageRankState(g, 8, r, nranks, options) for r in range(nranks)]
+        C = chunks if options == 7 else 1
+        for s in states:
+            s.set_chunks(C)
+            s.reset(0.85)
+        n = torch.as_tensor(states[0].contrib_slice(), device="cuda").numel()
+        need = states[0].exchange_count()
+
+        def exchange(bufs):
+            for dst_t in bufs:
+                for r, src_t in enumerate(bufs):
+                    if dst_t is not src_t:
+                        dst_t[r * n:r * n + need].copy_(src_t[r * n:r * n + need])
+            torch.cuda.synchronize()
+
+        exchange([torch.as_tensor(s.contrib_full(), device="cuda") for s in states])
+        for _ in range(iters):
+            nxt = [torch.as_tensor(s.contrib_next_full(), device="cuda") for s in states]
+            for s in states:
+                s.step()
+            exchange(nxt)
+        out = np.zeros(og.N)
+        for s in states:
+            s.download(out)
+        if V:
+            assert rel_err(out, want) < 5e-12, (options, rel_err(out, want))
+        diff = sum(s.diff() for s in states)
+        assert abs(diff - want_diff) <= 1e-9 * max(want_diff, 1e-30) + 1e-15
+        for s in states:
+            s.free()
+    g.free()
+
+
 def test_edge_case_empty_graphs(gmx):
     for V in (0, 1, 5):
         begin = np.zeros(V + 1, np.int32)
