@@ -146,21 +146,20 @@ __global__ void bfs_level_queue_kernel(const int32_t* __restrict__ dist, int64_t
     }
 }
 
-// queue of the vertices whose bit is set (the frontier a bottom-up level left behind): 8 bytes per 64 vertices
-// to read instead of their dist[] entries
-__global__ void bfs_bitmap_queue_kernel(const unsigned long long* __restrict__ bm64, int64_t V,
+// queue of the vertices whose bit is set (the frontier a bottom-up level left behind): one thread per 64-bit
+// word -- 8 bytes per 64 vertices to read instead of their dist[] entries, and nothing to do for empty words
+__global__ void bfs_bitmap_queue_kernel(const unsigned long long* __restrict__ bm64, int64_t words,
                                         int32_t* __restrict__ q, unsigned long long* __restrict__ qcount) {
-    int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
-    const int64_t vend = (V + 63) / 64 * 64;
-    for (; v < vend; v += stride) {
-        const unsigned long long m = bm64[v >> 6];      // one word per wave (v is lane-aligned)
-        if (m) {
-            const int lane = threadIdx.x & 63;
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(qcount, (unsigned long long) __popcll(m));
-            base = __shfl(base, 0, 64);
-            if ((m >> lane) & 1ULL) q[base + __popcll(m & ((1ULL << lane) - 1))] = (int32_t) v;
+    for (; w < words; w += stride) {
+        unsigned long long m = bm64[w];
+        if (!m) continue;
+        unsigned long long at = atomicAdd(qcount, (unsigned long long) __popcll(m));
+        while (m) {
+            const int b = __ffsll((long long) m) - 1;
+            m &= m - 1;
+            q[at++] = (int32_t) (w * 64 + b);
         }
     }
 }
@@ -383,8 +382,8 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
         if (b->frontier_is_bitmap) {   // back from bottom-up: rebuild the queue and its edge offsets
             GMX_HIP(hipMemsetAsync(b->qcount.p, 0, sizeof(unsigned long long), 0));
             if (b->frontier_bm_valid)   // the frontier is the bitmap the last bottom-up level found
-                hipLaunchKernelGGL(bfs_bitmap_queue_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
-                                   (const unsigned long long*) b->bm[b->fr].p, V, b->cur_q, b->qcount.p);
+                hipLaunchKernelGGL(bfs_bitmap_queue_kernel, dim3(grid_for((V + 63) / 64, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
+                                   (const unsigned long long*) b->bm[b->fr].p, (V + 63) / 64, b->cur_q, b->qcount.p);
             else
                 hipLaunchKernelGGL(bfs_level_queue_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
                                    (const int32_t*) b->dist.p, V, b->level, b->cur_q, b->qcount.p);
