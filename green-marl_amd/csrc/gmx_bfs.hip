@@ -794,6 +794,110 @@ static int expand_selected(gmx_graph* g, const int32_t* prop, int filter, int32_
     return GMX_OK;
 }
 
+// Pull formulation with the predicate as a bitmap (V/8 bytes: resident in every L2): a row walks its neighbour
+// list and probes the bitmap -- no atomics, no gathers from a V-sized array.  Rows longer than ROWCNT_LONG are
+// left to whole waves.  mode bits: 1 = count the neighbours whose bit is CLEAR (else set); rows are taken only
+// if their own bit in `row_bm` is set (row_bm == NULL: all rows).  Per-row counts go to cnt (if given), their
+// sum to total (if given).
+#define ROWCNT_LONG 256
+__global__ void pred_bitmap_kernel(const int32_t* __restrict__ prop, int64_t V, int filter, int32_t num, unsigned long long* __restrict__ bm64) {
+    int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    const int64_t vend = (V + 63) / 64 * 64;
+    for (; v < vend; v += stride) {
+        bool in = false;
+        if (v < V) {
+            const int32_t p = prop[v];
+            in = filter == 0 ? (p >= 10 && p < 20) : (p == num);
+        }
+        const unsigned long long m = __ballot(in);
+        if ((threadIdx.x & 63) == 0) bm64[v >> 6] = m;
+    }
+}
+
+__global__ void __launch_bounds__(BFS_THREADS)
+row_count_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ idx, int64_t V,
+                 const uint32_t* __restrict__ row_bm, const uint32_t* __restrict__ probe_bm, int invert,
+                 int32_t* __restrict__ cnt, int32_t* __restrict__ long_rows, unsigned long long* __restrict__ nlong,
+                 unsigned long long* __restrict__ total) {
+    int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    unsigned long long acc = 0;
+    for (; v < V; v += stride) {
+        if (row_bm && !((row_bm[v >> 5] >> (v & 31)) & 1u)) {
+            if (cnt) cnt[v] = 0;
+            continue;
+        }
+        const int32_t b = begin[v], e = begin[v + 1];
+        if (e - b > ROWCNT_LONG) {
+            long_rows[atomicAdd(nlong, 1ULL)] = (int32_t) v;
+            continue;
+        }
+        int32_t c = 0;
+        for (int32_t i = b; i < e; i++) {
+            const int32_t w = idx[i];
+            const unsigned bit = (probe_bm[w >> 5] >> (w & 31)) & 1u;
+            c += invert ? (int32_t) (bit ^ 1u) : (int32_t) bit;
+        }
+        if (cnt) cnt[v] = c;
+        acc += (unsigned long long) c;
+    }
+    if (total) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if ((threadIdx.x & 63) == 0 && acc) atomicAdd(total, acc);
+    }
+}
+
+__global__ void __launch_bounds__(BFS_THREADS)
+row_count_long_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ idx, const int32_t* __restrict__ long_rows,
+                      unsigned long long nlong, const uint32_t* __restrict__ probe_bm, int invert,
+                      int32_t* __restrict__ cnt, unsigned long long* __restrict__ total) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long wave = ((unsigned long long) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned long long nwaves = ((unsigned long long) gridDim.x * blockDim.x) >> 6;
+    unsigned long long acc = 0;
+    for (; wave < nlong; wave += nwaves) {
+        const int32_t v = long_rows[wave];
+        const int32_t b = begin[v], e = begin[v + 1];
+        unsigned long long c = 0;
+        for (int32_t i = b + lane; i < e; i += 64) {
+            const int32_t w = idx[i];
+            const unsigned bit = (probe_bm[w >> 5] >> (w & 31)) & 1u;
+            c += invert ? (bit ^ 1u) : bit;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+        if (lane == 0) {
+            if (cnt) cnt[v] = (int32_t) c;
+            acc += c;
+        }
+    }
+    if (total && lane == 0 && acc) atomicAdd(total, acc);
+}
+
+// rows (all, or those whose bit is set in row_bm) count their neighbours by the probe bitmap
+static int count_by_bitmap(const int32_t* begin, const int32_t* idx, int64_t V, const unsigned long long* row_bm,
+                           const unsigned long long* probe_bm, int invert, int32_t* cnt, unsigned long long* total) {
+    dbuf<int32_t> long_rows;
+    dbuf<unsigned long long> nlong;
+    GMX_CHECK(long_rows.alloc((size_t) V));
+    GMX_CHECK(nlong.alloc(1));
+    GMX_HIP(hipMemsetAsync(nlong.p, 0, sizeof(unsigned long long), 0));
+    hipLaunchKernelGGL(row_count_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 32)), dim3(BFS_THREADS), 0, 0, begin, idx, V,
+                       (const uint32_t*) row_bm, (const uint32_t*) probe_bm, invert, cnt, long_rows.p, nlong.p, total);
+    unsigned long long h = 0;
+    GMX_HIP(hipMemcpy(&h, nlong.p, sizeof(h), hipMemcpyDeviceToHost));
+    if (h) {
+        int64_t wb = (int64_t) ((h * 64 + BFS_THREADS - 1) / BFS_THREADS);
+        if (wb > 256 * 32) wb = 256 * 32;
+        hipLaunchKernelGGL(row_count_long_kernel, dim3((unsigned) wb), dim3(BFS_THREADS), 0, 0, begin, idx, (const int32_t*) long_rows.p, h,
+                           (const uint32_t*) probe_bm, invert, cnt, total);
+    }
+    GMX_HIP(hipGetLastError());
+    return GMX_OK;
+}
+
 extern "C" int gmx_avg_teen_cnt(gmx_graph_t* g, const int32_t* age_host, int32_t K, int32_t* teen_cnt_host, float* avg,
                                 gmx_stats_t* stats) {
     GMX_REQUIRE(g && avg && (teen_cnt_host || g->V == 0) && (age_host || g->V == 0), "NULL argument");
@@ -812,8 +916,16 @@ extern "C" int gmx_avg_teen_cnt(gmx_graph_t* g, const int32_t* age_host, int32_t
     GMX_HIP(hipEventRecord(ev[0], 0));
     GMX_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * (size_t) V, 0));
     GMX_HIP(hipMemsetAsync(acc.p, 0, 2 * sizeof(unsigned long long), 0));
-    // n.teen_cnt = Count(t: n.InNbrs)(t.age >= 10 && t.age < 20): one increment per out-edge of a teen
-    GMX_CHECK(expand_selected<0>(g, age.p, 0, 0, cnt.p, nullptr));
+    // n.teen_cnt = Count(t: n.InNbrs)(t.age >= 10 && t.age < 20)
+    if (g->has_reverse) {   // as written: every row walks its in-neighbours, the filter being a bitmap in the L2
+        dbuf<unsigned long long> teen;
+        GMX_CHECK(teen.alloc((size_t) ((V + 63) / 64)));
+        hipLaunchKernelGGL(pred_bitmap_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0, (const int32_t*) age.p, V, 0, 0, teen.p);
+        GMX_CHECK(count_by_bitmap(g->r_begin.p, g->r_node_idx.p, V, nullptr, teen.p, 0, cnt.p, nullptr));
+        GMX_HIP(hipDeviceSynchronize());   // (teen is released at the end of this block)
+    } else {                // forward CSR only: one increment per out-edge of a teen (integer atomics: same counts)
+        GMX_CHECK(expand_selected<0>(g, age.p, 0, 0, cnt.p, nullptr));
+    }
     // Avg(n: G.Nodes)(n.age > K){n.teen_cnt}: int32 sum, int64 count (gm_syntax_sugar2.cc:264-296)
     hipLaunchKernelGGL(filtered_sum_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, (const int32_t*) age.p, (const int32_t*) cnt.p,
                        (const int32_t*) nullptr, V, 0, K, acc.p);
@@ -855,7 +967,13 @@ extern "C" int gmx_conduct(gmx_graph_t* g, const int32_t* member_host, int32_t n
                            (const int32_t*) g->begin.p, V, 1, num, acc.p);
         hipLaunchKernelGGL(filtered_sum_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, (const int32_t*) member.p, (const int32_t*) nullptr,
                            (const int32_t*) g->begin.p, V, 2, num, acc.p + 2);
-        GMX_CHECK(expand_selected<1>(g, member.p, 1, num, nullptr, acc.p + 4));
+        {   // Cross: members count their out-neighbours that are not members (membership as a bitmap in the L2)
+            dbuf<unsigned long long> mem_bm;
+            GMX_CHECK(mem_bm.alloc((size_t) ((V + 63) / 64)));
+            hipLaunchKernelGGL(pred_bitmap_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0, (const int32_t*) member.p, V, 1, num, mem_bm.p);
+            GMX_CHECK(count_by_bitmap(g->begin.p, g->node_idx.p, V, mem_bm.p, mem_bm.p, 1, nullptr, acc.p + 4));
+            GMX_HIP(hipDeviceSynchronize());
+        }
         GMX_HIP(hipEventRecord(ev[1], 0));
         GMX_HIP(hipMemcpy(h, acc.p, sizeof(h), hipMemcpyDeviceToHost));
     }
