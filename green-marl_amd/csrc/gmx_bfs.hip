@@ -613,22 +613,29 @@ extern "C" int gmx_sssp(gmx_graph_t* g, gmx_node_t root, const int32_t* len_host
         GMX_HIP(hipMemcpy(q0.p, &root, sizeof(int32_t), hipMemcpyHostToDevice));
         cur_count = 1;
     }
+    // per-round read-backs through pinned memory (two host round trips per round, dozens of rounds)
+    bfs_counters* h_ctr = nullptr;
+    int64_t* h_mf = nullptr;
+    GMX_HIP(hipHostMalloc((void**) &h_ctr, sizeof(bfs_counters), hipHostMallocDefault));
+    GMX_HIP(hipHostMalloc((void**) &h_mf, sizeof(int64_t), hipHostMallocDefault));
+    GMX_HIP(hipMemsetAsync(ctr.p, 0, sizeof(bfs_counters), 0));
     while (cur_count > 0) {
-        bfs_counters zero = {0, edges};
-        GMX_HIP(hipMemcpy(ctr.p, &zero, sizeof(zero), hipMemcpyHostToDevice));
+        GMX_HIP(hipMemsetAsync(&ctr.p->next_count, 0, sizeof(unsigned long long), 0));   // `edges` keeps accumulating
         hipLaunchKernelGGL(bfs_degree_kernel, dim3(grid_for(cur_count)), dim3(BFS_THREADS), 0, 0, g->begin.p, cur_q, cur_count, deg.p);
         size_t tb = scan_bytes;
         GMX_HIP(rocprim::inclusive_scan(scan_tmp.p, tb, deg.p, off.p + 1, (size_t) cur_count, rocprim::plus<int64_t>(), 0));
         GMX_HIP(hipMemsetAsync(off.p, 0, sizeof(int64_t), 0));
-        int64_t m_f = 0;
-        GMX_HIP(hipMemcpy(&m_f, off.p + cur_count, sizeof(int64_t), hipMemcpyDeviceToHost));
+        GMX_HIP(hipMemcpyAsync(h_mf, off.p + cur_count, sizeof(int64_t), hipMemcpyDeviceToHost, 0));
+        GMX_HIP(hipStreamSynchronize(0));
+        const int64_t m_f = *h_mf;
         const int64_t nb = (cur_count + m_f + BFS_ITEMS - 1) / BFS_ITEMS;
         if (nb > 0)
             hipLaunchKernelGGL(sssp_relax_kernel, dim3((unsigned) nb), dim3(BFS_THREADS), 0, 0, g->begin.p, g->node_idx.p,
                                (const int32_t*) len.p, cur_q, cur_count, off.p, m_f, round, dist.p, stamp.p, next_q, ctr.p);
         GMX_HIP(hipGetLastError());
-        bfs_counters h;
-        GMX_HIP(hipMemcpy(&h, ctr.p, sizeof(h), hipMemcpyDeviceToHost));
+        GMX_HIP(hipMemcpyAsync(h_ctr, ctr.p, sizeof(bfs_counters), hipMemcpyDeviceToHost, 0));
+        GMX_HIP(hipStreamSynchronize(0));
+        const bfs_counters h = *h_ctr;
         cur_count = (int64_t) h.next_count;
         edges = h.edges;
         requeued += cur_count;
@@ -639,6 +646,8 @@ extern "C" int gmx_sssp(gmx_graph_t* g, gmx_node_t root, const int32_t* len_host
     }
     GMX_HIP(hipEventRecord(ev[1], 0));
     GMX_HIP(hipEventSynchronize(ev[1]));
+    (void) hipHostFree(h_ctr);
+    (void) hipHostFree(h_mf);
     GMX_HIP(hipMemcpy(dist_host, dist.p, sizeof(int32_t) * (size_t) V, hipMemcpyDeviceToHost));
     if (stats) {
         float ms = 0, hms = 0;
