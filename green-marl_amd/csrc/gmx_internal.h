@@ -99,6 +99,28 @@ int gmx_keys_from_csr(const int32_t* begin, const int32_t* idx, int64_t V, int64
 int gmx_keys_from_edges(const int32_t* src, const int32_t* dst, int64_t E, bool transpose,
                         const int32_t* perm, uint64_t* keys, hipStream_t stream);
 
+// ---- cold-source part of the PageRank sweep (gmx_pr_cold.hip) ----
+// Sources whose id inside their rank range [r * slice, (r + 1) * slice) is >= T are "cold": their edges are not
+// gathered by the pull sweep but pushed through plan-time-ordered bins (see gmx_pr_cold.hip).
+struct pr_cold;
+struct pr_cold_params {
+    int elem;        // 4 (float) or 8 (double)
+    int nranks;
+    int64_t slice;   // ids per rank range of the contribution replica
+    int64_t T;       // hot ids per rank range
+    int64_t row_lo;  // first owned row (internal numbering)
+    int64_t nactive; // owned rows with in-edges
+    const int32_t* index_of_row;   // [rows] local row -> position in the active-row list (device)
+};
+// keys[Ec]: (row << 32 | source) of the cold in-edges of the owned rows, any order (device).
+int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, hipStream_t s, pr_cold** out);
+void pr_cold_free(pr_cold* c);
+// enqueue phases 1-3: reads the contribution replica, leaves the cold row sums in pr_cold_partial()
+int pr_cold_launch(pr_cold* c, const void* contrib, hipStream_t s);
+const void* pr_cold_partial(const pr_cold* c);   // [nactive] x elem, indexed like the per-slice partial sums
+int64_t pr_cold_edges(const pr_cold* c);
+int64_t pr_cold_items(const pr_cold* c);
+
 static inline int gmx_bits_for(int64_t v) {  // bits needed to represent values in [0, v)
     int b = 1;
     while ((1LL << b) < v && b < 32) b++;

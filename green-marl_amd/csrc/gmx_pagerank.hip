@@ -117,6 +117,10 @@ struct gmx_pr {
     dbuf<char> sl_partial;
     dbuf<unsigned int> sl_queue;
     int64_t sl_nblk_total = 0;
+    // cold sources (local id >= cold_T in their rank range): their edges bypass the pull sweep (gmx_pr_cold.hip)
+    pr_cold* cold = nullptr;
+    int64_t cold_T = -1;      // hot ids per rank range; -1: no binned part, 0: every edge is binned
+    int64_t Eh = 0;           // edges the pull sweep reduces (El minus the cold ones)
     // peer push (exchange over xGMI by the copy engines): the other ranks' replicas mapped into this
     // process, one copy stream per peer
     int step_next = 1;                       // replica the running step writes
@@ -140,6 +144,7 @@ struct gmx_pr {
             if (e) (void) hipEventDestroy(e);
         if (push_ready) (void) hipEventDestroy(push_ready);
         if (h_diff) (void) hipHostFree(h_diff);
+        pr_cold_free(cold);
     }
 };
 
@@ -314,6 +319,12 @@ __global__ void pr_blocks_kernel(const int32_t* __restrict__ rb, int64_t rows, i
     blk[k].r = (int32_t) lo;
     blk[k].e = (int32_t) (dk - lo);
 }
+
+// selects the in-edges the pull sweep keeps: source inside the hot prefix of its rank range
+struct pr_is_hot_key {
+    uint32_t slice, T;
+    __device__ bool operator()(const uint64_t& k) const { return ((uint32_t) k) % slice < T; }
+};
 
 // ------------------------------------------------------------------ hot loop
 template <typename S>
@@ -913,7 +924,7 @@ __global__ void pr_sliced_fixup_kernel(pr_sliced_args a, int64_t rows) {
 template <typename S>
 __global__ void __launch_bounds__(256)
 pr_combine_kernel(pr_sliced_args a, const int32_t* __restrict__ active, int64_t i_lo, int64_t i_hi,
-                  const int32_t* __restrict__ outdeg_c, S* __restrict__ rk_c,
+                  const int32_t* __restrict__ outdeg_c, S* __restrict__ rk_c, const S* __restrict__ cold,
                   S* __restrict__ contrib_next_owned, double base, double d, double* __restrict__ diff_part) {
     __shared__ double s_red[256 / 64];
     double diff_acc = 0.0;
@@ -923,6 +934,7 @@ pr_combine_kernel(pr_sliced_args a, const int32_t* __restrict__ active, int64_t 
         const int64_t r = __builtin_nontemporal_load(active + i);
         double sum = 0.0;
         for (int sl = 0; sl < a.ns; sl++) sum += (double) __builtin_nontemporal_load((const S*) a.s[sl].partial + i);
+        if (cold) sum += (double) __builtin_nontemporal_load(cold + i);   // the cold sources' part, after the slices
         const int32_t od = __builtin_nontemporal_load(outdeg_c + i);
         const double val = base + d * sum;
         const double old = (double) __builtin_nontemporal_load(rk_c + i);
@@ -1194,23 +1206,62 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
             int64_t hb[2] = {0, 0};
             if (hipMemcpy(hb, bounds.p, sizeof(hb), hipMemcpyDeviceToHost) != hipSuccess) { gmx_set_error("pr plan: bounds copy failed"); st = GMX_ERR_HIP; break; }
             p->El = hb[1] - hb[0];
+            p->Eh = p->El;
             if (p->ns > 0) {
-                // group the owned keys by source slice (stable 1-pass radix sort on the slice number)
                 const int ns = p->ns;
-                const int64_t El = p->El, rows = p->rows;
+                const int64_t rows = p->rows;
+                // ---- cold sources: ids >= cold_T inside their rank range leave the pull sweep ----
+                const uint64_t* own = sorted + hb[0];   // all in-edges of the owned rows, (row, source) ascending
+                const uint64_t* hk = own;               // the ones the pull sweep keeps
+                const uint64_t* cold_keys = nullptr;
+                int64_t Ec = 0;
+                p->cold_T = -1;
+                if (options & GMX_PR_COLD_PB) {
+                    // default 0: every edge is binned.  Measured on RMAT-26 fp32 (profiles/round2_*): 2.25 ms per
+                    // iteration, against 3.57 with the 180 K hottest sources (the ones the LDS tiles of the pull sweep
+                    // hold) left to the pull sweep, 4.08 with the first 1 Mi (what the L2s hold), 4.76 without bins
+                    const int64_t unit = (int64_t) ns << PR_RUN_SHIFT;
+                    int64_t T = 0;
+                    const char* ev = getenv("GMX_PR_COLD");
+                    if (ev && *ev) T = atoll(ev);
+                    T = T / unit * unit;
+                    // worth it only with at least a few LDS tiles of cold sources
+                    const int64_t margin = unit;
+                    if (T >= 0 && T + margin <= p->slice && p->El > 0) p->cold_T = T;
+                }
+                if (p->cold_T >= 0) {
+                    uint64_t* other = (sorted == keys.p) ? alt.p : keys.p;
+                    dbuf<int64_t> nsel;
+                    if ((st = nsel.alloc(1))) break;
+                    pr_is_hot_key pred{(uint32_t) p->slice, (uint32_t) p->cold_T};
+                    size_t tb = 0;
+                    hipError_t he = rocprim::partition(nullptr, tb, own, other, nsel.p, (size_t) p->El, pred, s);
+                    dbuf<char> tmp;
+                    if (he == hipSuccess && (st = tmp.alloc(tb))) break;
+                    if (he == hipSuccess) he = rocprim::partition((void*) tmp.p, tb, own, other, nsel.p, (size_t) p->El, pred, s);
+                    int64_t nh = 0;
+                    if (he == hipSuccess) he = hipMemcpy(&nh, nsel.p, sizeof(int64_t), hipMemcpyDeviceToHost);
+                    if (he != hipSuccess) { gmx_set_error("pr plan: hot/cold partition failed: %s", hipGetErrorString(he)); st = GMX_ERR_HIP; break; }
+                    hk = other;                 // selected keys keep their order
+                    p->Eh = nh;
+                    cold_keys = other + nh;     // rejected keys (reversed): any order will do
+                    Ec = p->El - nh;
+                }
+                // group the kept keys by source slice (stable 1-pass radix sort on the slice number)
+                const int64_t El = p->Eh;
                 dbuf<uint8_t> sk, sk2;
                 dbuf<uint64_t> vals;
                 dbuf<int64_t> off;
                 if ((st = sk.alloc((size_t) El)) || (st = sk2.alloc((size_t) El)) || (st = vals.alloc((size_t) El)) ||
                     (st = off.alloc(PR_MAX_SLICES + 1))) break;
-                hipLaunchKernelGGL(pr_slice_key_kernel, dim3(grid_for(El)), dim3(256), 0, s, sorted + hb[0], El, ns, sk.p);
+                hipLaunchKernelGGL(pr_slice_key_kernel, dim3(grid_for(El)), dim3(256), 0, s, hk, El, ns, sk.p);
                 hipError_t he = hipSuccess;
                 if (El > 0) {
                     size_t tb = 0;
-                    he = rocprim::radix_sort_pairs(nullptr, tb, sk.p, sk2.p, sorted + hb[0], vals.p, (size_t) El, 0u, 3u, s);
+                    he = rocprim::radix_sort_pairs(nullptr, tb, sk.p, sk2.p, hk, vals.p, (size_t) El, 0u, 3u, s);
                     dbuf<char> tmp;
                     if (he == hipSuccess && (st = tmp.alloc(tb))) break;
-                    if (he == hipSuccess) he = rocprim::radix_sort_pairs((void*) tmp.p, tb, sk.p, sk2.p, sorted + hb[0], vals.p, (size_t) El, 0u, 3u, s);
+                    if (he == hipSuccess) he = rocprim::radix_sort_pairs((void*) tmp.p, tb, sk.p, sk2.p, hk, vals.p, (size_t) El, 0u, 3u, s);
                     if (he == hipSuccess) he = hipStreamSynchronize(s);
                 }
                 if (he != hipSuccess) { gmx_set_error("pr plan: slice sort failed: %s", hipGetErrorString(he)); st = GMX_ERR_HIP; break; }
@@ -1221,7 +1272,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 {
                     if ((st = p->sl_is_active.alloc((size_t) (rows ? rows : 1))) || (st = p->sl_active.alloc((size_t) (rows ? rows : 1)))) break;
                     if (hipMemsetAsync(p->sl_is_active.p, 0, (size_t) (rows ? rows : 1), s) != hipSuccess) { gmx_set_error("pr plan: memset failed"); st = GMX_ERR_HIP; break; }
-                    if (El > 0) hipLaunchKernelGGL(pr_mark_active_kernel, dim3(grid_for(El)), dim3(256), 0, s, sorted + hb[0], El, p->row_lo, p->sl_is_active.p);
+                    if (p->El > 0) hipLaunchKernelGGL(pr_mark_active_kernel, dim3(grid_for(p->El)), dim3(256), 0, s, own, p->El, p->row_lo, p->sl_is_active.p);
                     dbuf<int64_t> cnt;
                     if ((st = cnt.alloc(1))) break;
                     size_t tb = 0;
@@ -1266,9 +1317,9 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 hipLaunchKernelGGL(pr_slice_pairs_kernel, dim3(grid_for(El)), dim3(256), 0, s, (const uint64_t*) vals.p,
                                    (const uint8_t*) sk2.p, (const int32_t*) flag.p, (const int32_t*) pos.p, (const int64_t*) off.p,
                                    El, p->row_lo, p->sl_rowid.p, p->sl_rb.p);
+                dbuf<int32_t> index_of_row;
                 {   // name the compact rows by their position in active[] and make the dense per-active-row copies
                     const size_t na = (size_t) (p->sl_nactive ? p->sl_nactive : 1);
-                    dbuf<int32_t> index_of_row;
                     if ((st = index_of_row.alloc((size_t) (rows ? rows : 1))) || (st = p->sl_outdeg_c.alloc(na)) ||
                         (st = p->sl_rk_c.alloc(na * elem_bytes))) break;
                     if (p->sl_nactive > 0) {
@@ -1280,6 +1331,10 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                                            (const int32_t*) p->sl_active.p, p->sl_nactive, (const int32_t*) p->outdeg.p, p->sl_outdeg_c.p);
                     }
                     if (hipStreamSynchronize(s) != hipSuccess) { gmx_set_error("pr plan: active-row renaming failed"); st = GMX_ERR_HIP; break; }
+                }
+                if (p->cold_T >= 0) {   // tile- and bin-major streams of the binned edges
+                    pr_cold_params cp{elem_bytes, nranks, p->slice, p->cold_T, p->row_lo, p->sl_nactive, index_of_row.p};
+                    if ((st = pr_cold_create(cold_keys, Ec, cp, s, &p->cold))) break;
                 }
                 int64_t nblk_s[PR_MAX_SLICES], blk_off[PR_MAX_SLICES + 1];
                 blk_off[0] = 0;
@@ -1470,6 +1525,8 @@ static void launch_sliced_chunk(gmx_pr* p, int c, hipStream_t s) {
     const int j = C - 1 - c;
     S* next_owned = (S*) p->contrib[1 - p->cur].p + p->row_lo;
     pr_sliced_args a = p->sl;
+    // the cold sources' row sums of ALL rows, once per step, before the first chunk is combined
+    if (c == 0 && p->cold) (void) pr_cold_launch(p->cold, p->contrib[p->cur].p, s);
     int64_t maxfix = 0, total_blk = 0;
     for (int q = 0; q < p->ns; q++) {
         pr_slice_desc& sd = a.s[q];
@@ -1525,8 +1582,10 @@ static void launch_sliced_chunk(gmx_pr* p, int c, hipStream_t s) {
     if (maxfix > 0)
         hipLaunchKernelGGL(pr_sliced_fixup_kernel<S>, dim3((unsigned) ((maxfix + 255) / 256), p->ns), dim3(256), 0, s, a, p->rows);
     double* dpart = p->diff_part.p + (int64_t) c * 2 * PR_COMBINE_GRID;
+    if (p->Eh == 0) a.ns = 0;   // every edge is binned: nothing to add but the binned sums
     hipLaunchKernelGGL(pr_combine_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, a, (const int32_t*) p->sl_active.p,
-                       p->ch_act[j], p->ch_act[j + 1], (const int32_t*) p->sl_outdeg_c.p, (S*) p->sl_rk_c.p, next_owned, base, p->d, dpart);
+                       p->ch_act[j], p->ch_act[j + 1], (const int32_t*) p->sl_outdeg_c.p, (S*) p->sl_rk_c.p,
+                       (const S*) pr_cold_partial(p->cold), next_owned, base, p->d, dpart);
     if (p->cnt == 0) {   // first sweep after a reset: settle the rows without in-edges once
         hipLaunchKernelGGL(pr_inactive_first_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, (const uint8_t*) p->sl_is_active.p,
                            p->ch_row[j], p->ch_row[j + 1], p->outdeg.p, (S*) p->rk.p, next_owned, base, p->d,
@@ -1782,7 +1841,7 @@ extern "C" int gmx_pr_download(gmx_pr_t* p, void* rank_host) {
 extern "C" uint32_t gmx_pr_default_options(int64_t V, int nranks) {
     uint32_t o = GMX_PR_RELABEL;
     if (V > (1LL << 18)) o |= GMX_PR_HOT_LDS;   // with several ranks the tile is only used by the sliced kernel
-    if (V > (1LL << 21)) o |= GMX_PR_SLICED;
+    if (V > (1LL << 21)) o |= GMX_PR_SLICED | GMX_PR_COLD_PB;   // the cold part only exists past ~3.5 M vertices per rank
     return o;
 }
 
@@ -1809,6 +1868,8 @@ extern "C" int gmx_pr_kernel_time(gmx_pr_t* p, int32_t* launches, double* mean_m
 
 extern "C" const char* gmx_pr_kernel_name(gmx_pr_t* p) {
     if (!p) return "";
+    if (p->ns > 0 && p->cold)
+        return "pr_cold_gather_kernel+pr_cold_accum_kernel+pr_cold_reduce_kernel+pr_wave_sliced_kernel+pr_sliced_fixup_kernel+pr_combine_kernel+pr_diff_reduce_kernel";
     if (p->ns > 0) return "pr_wave_sliced_kernel+pr_sliced_fixup_kernel+pr_combine_kernel+pr_diff_reduce_kernel";
     return "pr_wave_kernel+pr_fixup_kernel+pr_diff_reduce_kernel";
 }
@@ -1819,6 +1880,14 @@ extern "C" int gmx_pr_work(gmx_pr_t* p, int64_t* edges, int64_t* rows, int64_t* 
     if (rows) *rows = p->rows_real;
     // E*(4+s) + V*(8+3s)
     if (algorithmic_bytes) *algorithmic_bytes = p->El * (4 + p->elem) + p->rows_real * (8 + 3 * (int64_t) p->elem);
+    return GMX_OK;
+}
+
+extern "C" int gmx_pr_cold_info(gmx_pr_t* p, int64_t* hot_ids, int64_t* cold_edges, int64_t* padded_items) {
+    GMX_REQUIRE(p, "pr is NULL");
+    if (hot_ids) *hot_ids = p->cold ? p->cold_T : -1;
+    if (cold_edges) *cold_edges = pr_cold_edges(p->cold);
+    if (padded_items) *padded_items = pr_cold_items(p->cold);
     return GMX_OK;
 }
 

@@ -1,0 +1,913 @@
+// gmx_pr_cold.hip -- the binned part of the PageRank sweep: tile-gather / bin-accumulate.
+//
+// The pull sweep of gmx_pagerank.hip gathers contrib[w] per in-edge (emitted loop:
+// /root/reference/apps/src/pagerank.gm:10-17, `Sum(w: t.InNbrs){w.pg_rank / w.OutDegree()}`) through a 32-bit
+// index; a gather that misses the XCD's L2 costs a whole 128-byte line for 4 useful bytes, and one that hits is
+// still an L2 request of its own.  The graph is static, so the in-edges whose source is past the first T ids of
+// its rank range (T = 0: all of them) are laid out at plan time so that NO gather leaves the CU:
+//
+//   tile-major   the sources are cut into TILES whose contributions fit the LDS (128 KiB); a tile's edges are
+//                ordered by destination BIN (BINROWS consecutive rows with in-edges -- "active" rows), then by
+//                row, and stored as 16 bits each: 15 bits of tile-local source number + 1 bit "last edge of its
+//                (tile, row) PAIR".  A (tile, bin) CELL is padded to whole groups of PRC_G edges.
+//   bin-major    one item per pair: 16-bit bin-local row number + the value slot that phase 1 fills; a cell's items
+//                are contiguous in both orders, a bin's cells follow each other.
+//
+//   phase 1  one workgroup per tile (big tiles are cut into chunks): contribution tile -> LDS (coalesced), then
+//            * pr_cold_pair_kernel  (tiles whose pairs average >= 1.25 edges -- the hot sources): every wave takes
+//              blocks of 512 edges, a lane 8 consecutive ones (one 16-byte load), gathers from LDS, sums in fp64
+//              along the lane, closes pairs that span lanes with a segmented wave scan (__shfl_up) and stores one
+//              value per pair.  Pairs are cut at block ends at plan time (a longer pair simply becomes several
+//              items of the same row), so a block needs nothing from its neighbours: no fix-up pass.
+//            * pr_cold_gather_kernel (tiles where almost every pair is a single edge -- the cold tail): every edge is
+//              an item; 8 lanes copy a group with one 8-byte load, four LDS reads and one 16-byte store each, so
+//              every store instruction writes whole aligned 128-byte lines.
+//            The only metadata is one int per group of 32 edges (slot of the first pair that ends in the group).
+//   phase 2  pr_cold_accum_kernel: one workgroup per bin (hub bins are split into chunks): streams values + 16-bit
+//            row numbers (coalesced) and adds into 64-bit FIXED-POINT accumulators in LDS.  Integer adds commute,
+//            so the result does not depend on the order the lanes arrive in: bit-reproducible without ordering
+//            anything.  fp32 values: one limb, 2^-62 resolution (fp32 keeps 24 bits; the smallest contribution of
+//            an RMAT-26 run is ~2^-34).  fp64 values: two limbs (2^-62 and 2^-(62+lo_bits)), > 100 bits below 1.0.
+//   phase 3  pr_cold_reduce_kernel adds the chunk accumulators of the split bins.
+//
+// Output: cold[i], the sum over the binned in-neighbours of active row i, element type S, which
+// pr_combine_kernel adds after the per-slice sums of the pull sweep (fixed order).
+// HBM bytes (fp32): 2.125 per edge + 10 per pair (4 written, 4 + 2 read), instead of 4 + a gather per edge.
+#pragma clang fp contract(off)
+
+#include "gmx_internal.h"
+
+#include <algorithm>
+#include <rocprim/rocprim.hpp>
+
+#define PRC_G 32                 // edges / items per group (a cell is padded to whole groups)
+#define PRC_BLK_GROUPS 16        // groups per wave block of the pair kernel (512 edges); tiles start on block boundaries
+#define PRC_LDS_BYTES 131072     // contribution tile / accumulator array
+#define PRC_THREADS 1024
+#define PRC_WAVES (PRC_THREADS / 64)
+#define PRC_UNROLL 4             // pieces (8 groups = 256 items) a wave keeps in flight
+#define PRC_PAD 0xffffu          // row number of a padding item
+#define PRC_END 0x8000u          // "last edge of its pair" bit of a tile-major entry
+#define PRC_Q1P 0                // work counters, 256 bytes apart
+#define PRC_Q1E 64
+#define PRC_Q2 128
+
+struct prc_item1 { int32_t tile, g0, g1, pad; };          // phase 1: groups [g0, g1) of the tile-major stream
+struct prc_item2 { int32_t bin, g0, g1, slot; };          // phase 2: groups [g0, g1) of the bin-major stream; slot < 0: sole chunk
+struct prc_item3 { int32_t bin, slot0, nslots, pad; };    // phase 3: a split bin
+
+struct pr_cold {
+    pr_cold_params prm;
+    int64_t Ec = 0;          // edges handled here
+    int64_t P1 = 0;          // tile-major entries (edges + padding)
+    int64_t P2 = 0;          // bin-major items (pairs + padding)
+    int64_t npairs = 0;
+    int64_t ncold = 0;       // source positions
+    int tile = 0, binrows = 0, limbs = 1, lo_bits = 42;
+    int64_t ntiles = 0, nbins = 0, ncells = 0;
+    dbuf<uint16_t> srcl;     // [P1] tile-major: source number | PRC_END
+    dbuf<int32_t> ob;        // [P1 / G] item slot of the first pair that ends in the group
+    dbuf<uint16_t> rowl;     // [P2] bin-major row numbers
+    dbuf<char> val;          // [P2] x elem, bin-major: written by phase 1, read by phase 2
+    dbuf<char> cold;         // [nactive] x elem
+    dbuf<prc_item1> it1p, it1e;
+    dbuf<prc_item2> it2;
+    dbuf<prc_item3> it3;
+    int64_t n1p = 0, n1e = 0, n2 = 0, n3 = 0, nslots = 0;
+    dbuf<unsigned long long> scratch;   // [nslots][limbs][binrows]
+    dbuf<unsigned int> queue;           // [3 * 64]
+    int grid = 256;
+};
+
+static int prc_grid_for(int64_t n, int block = 256) {
+    int64_t b = (n + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > 256 * 16) b = 256 * 16;
+    return (int) b;
+}
+
+// ------------------------------------------------------------------ plan kernels
+// key' = tile | bin | bin-local row | tile-local source   (a tile holds tile_src = TILE - 1 sources: the last LDS
+// slot stays zero and is what padding entries point at)
+__global__ void prc_keys_kernel(const uint64_t* __restrict__ keys, int64_t n, pr_cold_params prm, int tile_src, int binrows,
+                                int binbits, uint64_t* __restrict__ out) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    const int64_t span = prm.slice - prm.T;
+    for (; i < n; i += stride) {
+        const uint64_t k = keys[i];
+        const int64_t row = (int64_t) (k >> 32) - prm.row_lo;
+        const int64_t src = (int64_t) (uint32_t) k;
+        const int64_t a = prm.index_of_row[row];
+        const int64_t cp = (src / prm.slice) * span + (src % prm.slice - prm.T);
+        const uint64_t t = (uint64_t) (cp / tile_src), sl = (uint64_t) (cp % tile_src);
+        const uint64_t b = (uint64_t) (a / binrows), rl = (uint64_t) (a % binrows);
+        out[i] = (t << (32 + binbits)) | (b << 32) | (rl << 16) | sl;
+    }
+}
+
+// cflag: first edge of a cell.  nat: last edge of a (tile, row) pair.  Both arrays have n + 1 entries (last = 0).
+__global__ void prc_flag_kernel(const uint64_t* __restrict__ k, int64_t n, int32_t* __restrict__ cflag, int32_t* __restrict__ nat) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i <= n; i += stride) {
+        if (i == n) { cflag[i] = 0; nat[i] = 0; continue; }
+        cflag[i] = (i == 0 || (k[i] >> 32) != (k[i - 1] >> 32)) ? 1 : 0;
+        nat[i] = (i == n - 1 || (k[i] >> 16) != (k[i + 1] >> 16)) ? 1 : 0;
+    }
+}
+
+// first[c] = position of the first edge of cell c (first[ncells] = n); ckey[c] = tile | bin
+__global__ void prc_cell_first_kernel(const uint64_t* __restrict__ k, const int32_t* __restrict__ cflag,
+                                      const int32_t* __restrict__ incl, int64_t n, int64_t ncells, int32_t* __restrict__ first,
+                                      uint32_t* __restrict__ ckey) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i <= n; i += stride) {
+        if (i == n) { first[ncells] = (int32_t) n; continue; }
+        if (cflag[i]) {
+            first[incl[i] - 1] = (int32_t) i;
+            ckey[incl[i] - 1] = (uint32_t) (k[i] >> 32);
+        }
+    }
+}
+
+// groups[c] = ceil(count / G) where count = pre[first[c + 1]] - pre[first[c]] (pre == NULL: the edges themselves);
+// groups[ncells] = 0.  Optionally the raw counts too.
+__global__ void prc_cell_groups_kernel(const int32_t* __restrict__ first, const int32_t* __restrict__ pre, int64_t ncells,
+                                       int32_t* __restrict__ groups, int32_t* __restrict__ counts) {
+    int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; c <= ncells; c += stride) {
+        int32_t cnt = 0;
+        if (c < ncells) cnt = pre ? pre[first[c + 1]] - pre[first[c]] : first[c + 1] - first[c];
+        groups[c] = (cnt + PRC_G - 1) / PRC_G;
+        if (counts) counts[c] = cnt;
+    }
+}
+
+// per tile t (0..ntiles): index of its first cell, and the raw group / natural pair / edge prefix there
+__global__ void prc_tile_table_kernel(const uint32_t* __restrict__ ckey, int64_t ncells, int binbits, int64_t ntiles,
+                                      const int32_t* __restrict__ c1raw, const int32_t* __restrict__ natpre,
+                                      const int32_t* __restrict__ first, int32_t* __restrict__ out) {
+    int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; t <= ntiles; t += stride) {
+        int64_t lo = 0, hi = ncells;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t) (ckey[mid] >> binbits) < t) lo = mid + 1; else hi = mid;
+        }
+        out[4 * t + 0] = (int32_t) lo;
+        out[4 * t + 1] = c1raw[lo];            // arrays have ncells + 1 entries
+        out[4 * t + 2] = natpre[first[lo]];
+        out[4 * t + 3] = first[lo];
+    }
+}
+
+// c1[c] = c1raw[c] + delta[tile(c)]: tiles start on block boundaries
+__global__ void prc_cell_start_kernel(const int32_t* __restrict__ c1raw, const uint32_t* __restrict__ ckey, int binbits,
+                                      const int32_t* __restrict__ delta, int64_t ncells, int32_t* __restrict__ c1) {
+    int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; c < ncells; c += stride) c1[c] = c1raw[c] + delta[ckey[c] >> binbits];
+}
+
+// final end flags (in place over nat): pair tiles cut their pairs at the ends of the 512-entry blocks of the padded
+// stream; edge tiles make every edge an item
+__global__ void prc_final_flag_kernel(const int32_t* __restrict__ incl, const int32_t* __restrict__ first,
+                                      const int32_t* __restrict__ c1, const uint32_t* __restrict__ ckey, int binbits,
+                                      const uint8_t* __restrict__ pair_mode, int64_t n, int32_t* __restrict__ nat) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const int32_t c = incl[i] - 1;
+        const int64_t pos = (int64_t) c1[c] * PRC_G + (i - first[c]);
+        if (!pair_mode[ckey[c] >> binbits]) nat[i] = 1;
+        else if ((pos & (PRC_BLK_GROUPS * PRC_G - 1)) == PRC_BLK_GROUPS * PRC_G - 1) nat[i] = 1;
+    }
+}
+
+// key of the bin-major order of the cells
+__global__ void prc_cell_key2_kernel(const uint32_t* __restrict__ ckey, int64_t ncells, int binbits, int tilebits,
+                                     uint32_t* __restrict__ key2, int32_t* __restrict__ id) {
+    int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; c < ncells; c += stride) {
+        const uint32_t t = ckey[c] >> binbits, b = ckey[c] & ((1u << binbits) - 1);
+        key2[c] = (b << tilebits) | t;
+        id[c] = (int32_t) c;
+    }
+}
+
+__global__ void prc_gather_i32_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ idx, int64_t n, int32_t* __restrict__ dst) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = src[idx[i]];
+}
+__global__ void prc_scatter_i32_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ idx, int64_t n, int32_t* __restrict__ dst) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[idx[i]] = src[i];
+}
+__global__ void prc_fill_u16_kernel(uint16_t* __restrict__ p, int64_t n, uint16_t v) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+// edge i of cell c: entry srcl[c1[c] * G + o]; if it ends a pair, item rowl[c2[c] * G + (ends before it in the cell)]
+__global__ void prc_fill_items_kernel(const uint64_t* __restrict__ k, const int32_t* __restrict__ incl,
+                                      const int32_t* __restrict__ first, const int32_t* __restrict__ c1,
+                                      const int32_t* __restrict__ c2, const int32_t* __restrict__ endf,
+                                      const int32_t* __restrict__ endpre, int64_t n, uint16_t* __restrict__ srcl,
+                                      uint16_t* __restrict__ rowl) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const int32_t c = incl[i] - 1;
+        const int64_t o = i - first[c];
+        const uint32_t lo = (uint32_t) k[i];
+        srcl[(int64_t) c1[c] * PRC_G + o] = (uint16_t) ((lo & 0x7fffu) | (endf[i] ? PRC_END : 0u));
+        if (endf[i]) rowl[(int64_t) c2[c] * PRC_G + (endpre[i] - endpre[first[c]])] = (uint16_t) (lo >> 16);
+    }
+}
+
+// tile-major group g -> item slot of the first pair that ends in it (groups in the padding between tiles: 0, unused)
+__global__ void prc_fill_ob_kernel(const int32_t* __restrict__ c1, const int32_t* __restrict__ c2,
+                                   const int32_t* __restrict__ first, const int32_t* __restrict__ endpre, int64_t ncells,
+                                   int64_t ngroups, int32_t* __restrict__ ob) {
+    int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; g < ngroups; g += stride) {
+        int64_t lo = 0, hi = ncells;   // last cell with c1 <= g
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t) c1[mid] <= g) lo = mid + 1; else hi = mid;
+        }
+        const int64_t c = lo - 1;
+        int32_t v = 0;
+        if (c >= 0) {
+            const int64_t e0 = (int64_t) first[c] + (g - c1[c]) * PRC_G;
+            if (e0 < first[c + 1]) v = c2[c] * PRC_G + (endpre[e0] - endpre[first[c]]);
+        }
+        ob[g] = v;
+    }
+}
+
+// table[b] = first item group of the first cell (bin-major order) whose bin is >= b
+__global__ void prc_bin_table_kernel(const uint32_t* __restrict__ key2s, const int32_t* __restrict__ c2s, int64_t ncells,
+                                     int tilebits, int64_t ngroups, int64_t nbins, int32_t* __restrict__ table) {
+    int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; t <= nbins; t += stride) {
+        int64_t lo = 0, hi = ncells;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t) (key2s[mid] >> tilebits) < t) lo = mid + 1; else hi = mid;
+        }
+        table[t] = lo < ncells ? c2s[lo] : (int32_t) ngroups;
+    }
+}
+
+// ------------------------------------------------------------------ hot loop
+typedef unsigned int prc_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int prc_u32x4 __attribute__((ext_vector_type(4)));
+typedef float prc_f32x4 __attribute__((ext_vector_type(4)));
+typedef double prc_f64x4 __attribute__((ext_vector_type(4)));
+template <typename S> struct prc_vec4;
+template <> struct prc_vec4<float> { typedef prc_f32x4 type; };
+template <> struct prc_vec4<double> { typedef prc_f64x4 type; };
+
+__device__ __forceinline__ int64_t prc_id_of(int64_t cp, int64_t span, int64_t slice, int64_t T) {
+    return (cp / span) * slice + T + cp % span;
+}
+
+// contribution tile `tile` (TILE - 1 sources) -> LDS; the last slot is the zero that padding entries read
+template <typename S, int TILE>
+__device__ __forceinline__ void prc_load_tile(S* __restrict__ s_tile, int tile, const S* __restrict__ contrib,
+                                              int64_t ncold, int64_t span, int64_t slice, int64_t T) {
+    const int64_t cp0 = (int64_t) tile * (TILE - 1);
+#pragma unroll 4
+    for (int i = threadIdx.x; i < TILE; i += PRC_THREADS) {
+        const int64_t cp = cp0 + i;
+        s_tile[i] = (i < TILE - 1 && cp < ncold) ? __builtin_nontemporal_load(contrib + prc_id_of(cp, span, slice, T)) : (S) 0;
+    }
+}
+
+// wave-level data movement on the VALU (DPP): no LDS traffic next to the tile gathers
+#define PRC_DPP_ROW_SHR(n) (0x110 + (n))
+#define PRC_DPP_WAVE_SHR1 0x138
+#define PRC_DPP_BCAST15 0x142
+#define PRC_DPP_BCAST31 0x143
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int prc_dpp_i(int v) {   // lanes without a source (or outside ROW_MASK) read 0
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double prc_dpp_d(double v) {
+    const int lo = prc_dpp_i<CTRL, ROW_MASK>(__double2loint(v)), hi = prc_dpp_i<CTRL, ROW_MASK>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// one step of the segmented inclusive scan: (v, f) <- (f ? v : v + v', f | f') with the (v', f') the DPP pattern delivers
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void prc_seg_step(double& v, int& f) {
+    const double vo = prc_dpp_d<CTRL, ROW_MASK>(v);
+    const int fo = prc_dpp_i<CTRL, ROW_MASK>(f);
+    if (!f) v += vo;
+    f |= fo;
+}
+
+// one block of the pair form: 8 entries of this lane in `cur`, `o` = slot of the first pair that ends in the lane's group
+template <typename S>
+__device__ __forceinline__ void prc_pair_block(const S* __restrict__ s_tile, const prc_u32x4 cur, const int32_t o,
+                                               S* __restrict__ val, const int lane) {
+    const unsigned w[4] = {cur.x, cur.y, cur.z, cur.w};
+    double sum[8];
+    unsigned fl = 0;
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const unsigned e = (w[u >> 1] >> (16 * (u & 1))) & 0xffffu;
+        acc += (double) s_tile[e & 0x7fffu];
+        sum[u] = acc;
+        if (e & PRC_END) {
+            fl |= 1u << u;
+            acc = 0.0;
+        }
+    }
+    // open sums across lanes: segmented inclusive scan (a lane holding a pair end restarts the segment); four steps
+    // inside the rows of 16 lanes, then the row totals travel to the later rows
+    double v = acc;
+    int f = fl != 0;
+    prc_seg_step<PRC_DPP_ROW_SHR(1), 0xf>(v, f);
+    prc_seg_step<PRC_DPP_ROW_SHR(2), 0xf>(v, f);
+    prc_seg_step<PRC_DPP_ROW_SHR(4), 0xf>(v, f);
+    prc_seg_step<PRC_DPP_ROW_SHR(8), 0xf>(v, f);
+    prc_seg_step<PRC_DPP_BCAST15, 0xa>(v, f);
+    prc_seg_step<PRC_DPP_BCAST31, 0xc>(v, f);
+    const double carry = prc_dpp_d<PRC_DPP_WAVE_SHR1, 0xf>(v);   // lane 0 reads 0: pairs never cross a block start
+    // slot of this lane's first pair end: the group's base + the ends of the group's earlier lanes
+    const int cnt = __builtin_popcount(fl);
+    const int c1 = prc_dpp_i<PRC_DPP_ROW_SHR(1), 0xf>(cnt), c2 = prc_dpp_i<PRC_DPP_ROW_SHR(2), 0xf>(cnt),
+              c3 = prc_dpp_i<PRC_DPP_ROW_SHR(3), 0xf>(cnt);
+    const int q = lane & 3;
+    S* dst = val + (int64_t) o + ((q >= 1 ? c1 : 0) + (q >= 2 ? c2 : 0) + (q >= 3 ? c3 : 0));
+    bool first = true;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        if (fl & (1u << u)) {
+            double x = sum[u];
+            if (first) x += carry;
+            first = false;
+            *dst++ = (S) x;
+        }
+    }
+}
+
+// Phase 1, pair form.  Work item = (tile, groups [g0, g1)), g0 and g1 on block boundaries.  A wave walks its blocks
+// PRC_PAIR_DEPTH at a time and keeps the entries of the next PRC_PAIR_DEPTH in flight (64 KiB per CU): the stream
+// comes from HBM, ~2 us away.
+#define PRC_PAIR_DEPTH 4
+template <typename S, int TILE>
+__global__ void __launch_bounds__(PRC_THREADS)
+pr_cold_pair_kernel(const prc_item1* __restrict__ items, int n_items, unsigned int* __restrict__ queue,
+                    const S* __restrict__ contrib, int64_t ncold, int64_t span, int64_t slice, int64_t T,
+                    const uint16_t* __restrict__ srcl, const int32_t* __restrict__ ob, S* __restrict__ val) {
+    __shared__ S s_tile[TILE];
+    __shared__ int s_item;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int loaded = -1;
+    for (;;) {
+        __syncthreads();   // everybody is done with s_item and the tile of the previous item
+        if (tid == 0) s_item = (int) atomicAdd(&queue[PRC_Q1P], 1u);
+        __syncthreads();
+        const int it = s_item;
+        if (it >= n_items) break;
+        const prc_item1 d = items[it];
+        const int nb = (d.g1 - d.g0) / PRC_BLK_GROUPS;
+        const prc_u32x4* in = (const prc_u32x4*) srcl + (int64_t) d.g0 * (PRC_G / 8) + lane;   // 8 entries per lane
+        const int32_t* obp = ob + d.g0 + (lane >> 2);
+        prc_u32x4 cur[PRC_PAIR_DEPTH], nxt[PRC_PAIR_DEPTH];
+        int32_t ocur[PRC_PAIR_DEPTH], onxt[PRC_PAIR_DEPTH];
+#pragma unroll
+        for (int j = 0; j < PRC_PAIR_DEPTH; j++) {   // the first blocks travel while the tile is loaded
+            const int b = wv + j * PRC_WAVES;
+            cur[j] = prc_u32x4{0, 0, 0, 0};
+            ocur[j] = 0;
+            if (b < nb) {
+                cur[j] = __builtin_nontemporal_load(in + (int64_t) b * 64);
+                ocur[j] = __builtin_nontemporal_load(obp + b * PRC_BLK_GROUPS);
+            }
+        }
+        if (d.tile != loaded) {   // (workgroup-uniform) chunks of one tile often follow each other
+            prc_load_tile<S, TILE>(s_tile, d.tile, contrib, ncold, span, slice, T);
+            loaded = d.tile;
+            __syncthreads();
+        }
+        for (int b0 = wv; b0 < nb; b0 += PRC_WAVES * PRC_PAIR_DEPTH) {
+#pragma unroll
+            for (int j = 0; j < PRC_PAIR_DEPTH; j++) {
+                const int b = b0 + (PRC_PAIR_DEPTH + j) * PRC_WAVES;
+                nxt[j] = prc_u32x4{0, 0, 0, 0};
+                onxt[j] = 0;
+                if (b < nb) {
+                    nxt[j] = __builtin_nontemporal_load(in + (int64_t) b * 64);
+                    onxt[j] = __builtin_nontemporal_load(obp + b * PRC_BLK_GROUPS);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PRC_PAIR_DEPTH; j++)
+                if (b0 + j * PRC_WAVES < nb) prc_pair_block<S>(s_tile, cur[j], ocur[j], val, lane);
+#pragma unroll
+            for (int j = 0; j < PRC_PAIR_DEPTH; j++) {
+                cur[j] = nxt[j];
+                ocur[j] = onxt[j];
+            }
+        }
+    }
+}
+
+// Phase 1, edge form: every entry is an item.  A lane handles 4 consecutive entries of one group: one 8-byte load,
+// four LDS reads, one 16/32-byte store; 8 lanes cover a group, a wave 8 groups ("piece") per instruction.
+template <typename S, int TILE>
+__global__ void __launch_bounds__(PRC_THREADS)
+pr_cold_gather_kernel(const prc_item1* __restrict__ items, int n_items, unsigned int* __restrict__ queue,
+                      const S* __restrict__ contrib, int64_t ncold, int64_t span, int64_t slice, int64_t T,
+                      const uint16_t* __restrict__ srcl, const int32_t* __restrict__ ob, S* __restrict__ val) {
+    typedef typename prc_vec4<S>::type V4;
+    __shared__ S s_tile[TILE];
+    __shared__ int s_item;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int loaded = -1;
+    for (;;) {
+        __syncthreads();   // everybody is done with s_item and the tile of the previous item
+        if (tid == 0) s_item = (int) atomicAdd(&queue[PRC_Q1E], 1u);
+        __syncthreads();
+        const int it = s_item;
+        if (it >= n_items) break;
+        const prc_item1 d = items[it];
+        if (d.tile != loaded) {
+            prc_load_tile<S, TILE>(s_tile, d.tile, contrib, ncold, span, slice, T);
+            loaded = d.tile;
+            __syncthreads();
+        }
+        const int npieces = (d.g1 - d.g0 + 7) >> 3;
+        for (int base = 0; base < npieces; base += PRC_WAVES * PRC_UNROLL) {
+            prc_u32x2 ids[PRC_UNROLL];
+            int32_t o[PRC_UNROLL];
+#pragma unroll
+            for (int u = 0; u < PRC_UNROLL; u++) {
+                const int pc = base + u * PRC_WAVES + wv;
+                const int g = d.g0 + pc * 8 + (lane >> 3);
+                o[u] = -1;
+                if (pc < npieces && g < d.g1) {
+                    ids[u] = __builtin_nontemporal_load((const prc_u32x2*) srcl + (int64_t) g * (PRC_G / 4) + (lane & 7));
+                    o[u] = __builtin_nontemporal_load(ob + g);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PRC_UNROLL; u++) {
+                if (o[u] < 0) continue;
+                V4 v;
+                v.x = s_tile[ids[u].x & 0x7fffu];
+                v.y = s_tile[(ids[u].x >> 16) & 0x7fffu];
+                v.z = s_tile[ids[u].y & 0x7fffu];
+                v.w = s_tile[(ids[u].y >> 16) & 0x7fffu];
+                __builtin_nontemporal_store(v, (V4*) (val + o[u]) + (lane & 7));   // o is a multiple of G: aligned lines
+            }
+        }
+    }
+}
+
+// value -> fixed point.  Contributions are in [0, 1] (rank <= 1, out-degree >= 1) and a row's cold terms add up
+// to at most the sum of all ranks (<= 1), so the 2^-62 limb cannot overflow; the second limb of the fp64 form
+// holds what the first one truncates, with lo_bits chosen at plan time from the largest number of terms.
+__device__ __forceinline__ unsigned long long prc_fix_hi(double v) { return (unsigned long long) (long long) (v * 0x1p62); }
+
+template <typename S, int BINROWS, int LIMBS>
+__global__ void __launch_bounds__(PRC_THREADS)
+pr_cold_accum_kernel(const prc_item2* __restrict__ items, int n_items, unsigned int* __restrict__ queue,
+                     const uint16_t* __restrict__ rowl, const S* __restrict__ val, int64_t nactive, double lo_scale,
+                     S* __restrict__ cold, unsigned long long* __restrict__ scratch) {
+    typedef typename prc_vec4<S>::type V4;
+    __shared__ unsigned long long s_acc[LIMBS * BINROWS];
+    __shared__ int s_item;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (;;) {
+        __syncthreads();   // the previous item has been flushed
+        if (tid == 0) s_item = (int) atomicAdd(&queue[PRC_Q2], 1u);
+#pragma unroll 4
+        for (int i = tid; i < LIMBS * BINROWS; i += PRC_THREADS) s_acc[i] = 0ull;
+        __syncthreads();
+        const int it = s_item;
+        if (it >= n_items) break;
+        const prc_item2 d = items[it];
+        const int npieces = (d.g1 - d.g0 + 7) >> 3;
+        for (int base = 0; base < npieces; base += PRC_WAVES * PRC_UNROLL) {
+            prc_u32x2 ids[PRC_UNROLL];
+            V4 v[PRC_UNROLL];
+            bool ok[PRC_UNROLL];
+#pragma unroll
+            for (int u = 0; u < PRC_UNROLL; u++) {
+                const int pc = base + u * PRC_WAVES + wv;
+                const int g = d.g0 + pc * 8 + (lane >> 3);
+                ok[u] = pc < npieces && g < d.g1;
+                if (ok[u]) {
+                    const int64_t at = (int64_t) g * (PRC_G / 4) + (lane & 7);
+                    ids[u] = __builtin_nontemporal_load((const prc_u32x2*) rowl + at);
+                    v[u] = __builtin_nontemporal_load((const V4*) val + at);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PRC_UNROLL; u++) {
+                if (!ok[u]) continue;
+                const unsigned r[4] = {ids[u].x & 0xffffu, ids[u].x >> 16, ids[u].y & 0xffffu, ids[u].y >> 16};
+                const double x[4] = {(double) v[u].x, (double) v[u].y, (double) v[u].z, (double) v[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (r[j] == PRC_PAD) continue;
+                    const unsigned long long hi = prc_fix_hi(x[j]);
+                    __hip_atomic_fetch_add(&s_acc[r[j]], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (LIMBS > 1) {
+                        const double rem = x[j] - (double) (long long) hi * 0x1p-62;   // exact: the bits hi dropped
+                        const unsigned long long lo = (unsigned long long) (long long) (rem * 0x1p62 * lo_scale);   // rem < 2^-62
+                        __hip_atomic_fetch_add(&s_acc[BINROWS + r[j]], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (d.slot < 0) {
+            const int64_t i0 = (int64_t) d.bin * BINROWS;
+#pragma unroll 4
+            for (int r = tid; r < BINROWS; r += PRC_THREADS) {
+                if (i0 + r >= nactive) break;
+                double s = (double) (long long) s_acc[r] * 0x1p-62;
+                if (LIMBS > 1) s += (double) (long long) s_acc[BINROWS + r] * (0x1p-62 / lo_scale);
+                __builtin_nontemporal_store((S) s, cold + i0 + r);
+            }
+        } else {
+            unsigned long long* dst = scratch + (int64_t) d.slot * (LIMBS * BINROWS);
+#pragma unroll 4
+            for (int i = tid; i < LIMBS * BINROWS; i += PRC_THREADS) dst[i] = s_acc[i];
+        }
+    }
+}
+
+// Phase 3.  A split bin's chunk accumulators (nslots x BINROWS, 128 KiB apart) are added per row: a block takes 64
+// consecutive rows (one 512-byte line set per slot and wave) and deals the slots to its 16 waves, which then meet
+// in LDS.  Integer adds: any order gives the same bits.
+template <typename S, int BINROWS, int LIMBS>
+__global__ void __launch_bounds__(1024)
+pr_cold_reduce_kernel(const prc_item3* __restrict__ items, int64_t nactive, double lo_scale,
+                      const unsigned long long* __restrict__ scratch, S* __restrict__ cold) {
+    __shared__ unsigned long long s_part[LIMBS][16][64];
+    const prc_item3 d = items[blockIdx.y];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 64 + lane;
+    const int64_t i0 = (int64_t) d.bin * BINROWS;
+    unsigned long long hi = 0, lo = 0;
+    const unsigned long long* src = scratch + (int64_t) d.slot0 * (LIMBS * BINROWS) + r;
+#pragma unroll 4
+    for (int s = wv; s < d.nslots; s += 16) {
+        hi += __builtin_nontemporal_load(src + (int64_t) s * (LIMBS * BINROWS));
+        if (LIMBS > 1) lo += __builtin_nontemporal_load(src + (int64_t) s * (LIMBS * BINROWS) + BINROWS);
+    }
+    s_part[0][wv][lane] = hi;
+    if (LIMBS > 1) s_part[LIMBS - 1][wv][lane] = lo;
+    __syncthreads();
+    if (wv == 0 && i0 + r < nactive) {
+        hi = 0;
+        lo = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            hi += s_part[0][w][lane];
+            if (LIMBS > 1) lo += s_part[LIMBS - 1][w][lane];
+        }
+        double v = (double) (long long) hi * 0x1p-62;
+        if (LIMBS > 1) v += (double) (long long) lo * (0x1p-62 / lo_scale);
+        cold[i0 + r] = (S) v;
+    }
+}
+
+// ------------------------------------------------------------------ plan
+#define PRC_TRY(expr, what)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            gmx_set_error("pr cold plan: %s failed: %s", what, hipGetErrorString(_e));       \
+            st = GMX_ERR_HIP;                                                                \
+            goto done;                                                                       \
+        }                                                                                    \
+    } while (0)
+#define PRC_ALLOC(buf, count)                        \
+    do {                                             \
+        if ((st = (buf).alloc((size_t) (count)))) goto done; \
+    } while (0)
+
+static int prc_env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// exclusive prefix sums of n int32 values (in != out)
+static hipError_t prc_exscan(const int32_t* in, int32_t* out, int64_t n, dbuf<char>& tmp, hipStream_t s) {
+    size_t tb = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, tb, in, out, 0, (size_t) n, rocprim::plus<int32_t>(), s);
+    if (e != hipSuccess) return e;
+    if (tmp.n < tb) {
+        tmp.release();
+        if (tmp.alloc(tb)) return hipErrorOutOfMemory;
+    }
+    return rocprim::exclusive_scan((void*) tmp.p, tb, in, out, 0, (size_t) n, rocprim::plus<int32_t>(), s);
+}
+
+int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, hipStream_t s, pr_cold** outp) {
+    *outp = nullptr;
+    GMX_REQUIRE(prm.elem == 4 || prm.elem == 8, "pr cold: bad element size");
+    GMX_REQUIRE(prm.T >= 0 && prm.T < prm.slice, "pr cold: threshold outside the rank range");
+    GMX_REQUIRE(Ec < (1LL << 31) - (1LL << 27), "pr cold: %lld edges exceed the int32 stream positions", (long long) Ec);
+    pr_cold* c = new pr_cold();
+    c->prm = prm;
+    c->Ec = Ec;
+    c->tile = PRC_LDS_BYTES / prm.elem;
+    const int tile_src = c->tile - 1;
+    c->limbs = prm.elem == 4 ? 1 : 2;
+    c->binrows = PRC_LDS_BYTES / 8 / c->limbs;
+    c->ncold = (int64_t) prm.nranks * (prm.slice - prm.T);
+    c->ntiles = (c->ncold + tile_src - 1) / tile_src;
+    c->nbins = (prm.nactive + c->binrows - 1) / c->binrows;
+    if (c->nbins < 1) c->nbins = 1;
+    const int tilebits = gmx_bits_for(c->ntiles), binbits = gmx_bits_for(c->nbins);
+    // an edge tile has pairs averaging fewer than this many edges (GMX_PR_COLD_PAIR_X100 overrides, in percent)
+    const double pair_min = prc_env_int("GMX_PR_COLD_PAIR_X100", 125) / 100.0;
+    int st = GMX_OK;
+    dbuf<uint64_t> k1, k2;
+    dbuf<int32_t> cflag, incl, nat, natpre, first, groups, c1raw, c1, ttab, delta, counts, id, order2, groups2, c2s, c2, tab2;
+    dbuf<uint32_t> ckey, key2, key2s;
+    dbuf<uint8_t> mode;
+    dbuf<char> tmp;
+    const uint64_t* sk = nullptr;
+    std::vector<int32_t> ht, hdelta, tstart, h2;
+    std::vector<uint8_t> hmode;
+    std::vector<prc_item1> v1p, v1e;
+    std::vector<prc_item2> v2;
+    std::vector<prc_item3> v3;
+    int64_t ngroups1 = 0, ngroups2 = 0, nc = 0, pair_edges = 0, pair_tiles = 0;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (tilebits + binbits > 32) {
+        gmx_set_error("pr cold: %lld tiles x %lld bins do not fit the sort key", (long long) c->ntiles, (long long) c->nbins);
+        st = GMX_ERR_ARG;
+        goto done;
+    }
+    PRC_ALLOC(c->cold, (size_t) (prm.nactive ? prm.nactive : 1) * prm.elem);
+    PRC_TRY(hipMemsetAsync(c->cold.p, 0, (size_t) (prm.nactive ? prm.nactive : 1) * prm.elem, s), "memset");
+    PRC_ALLOC(c->queue, 3 * 64);
+    PRC_TRY(hipMemsetAsync(c->queue.p, 0, 3 * 64 * sizeof(unsigned int), s), "memset");
+    (void) hipGetDevice(&dev);
+    PRC_TRY(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties");
+    c->grid = prop.multiProcessorCount;
+    if (Ec == 0) {
+        PRC_TRY(hipStreamSynchronize(s), "sync");
+        *outp = c;
+        return GMX_OK;
+    }
+    {   // ---- (tile, bin, row, source) keys, sorted ----
+        PRC_ALLOC(k1, Ec);
+        PRC_ALLOC(k2, Ec);
+        hipLaunchKernelGGL(prc_keys_kernel, dim3(prc_grid_for(Ec)), dim3(256), 0, s, keys, Ec, prm, tile_src, c->binrows, binbits, k1.p);
+        rocprim::double_buffer<uint64_t> db(k1.p, k2.p);
+        size_t tb = 0;
+        const unsigned end_bit = 32u + (unsigned) binbits + (unsigned) tilebits;
+        PRC_TRY(rocprim::radix_sort_keys(nullptr, tb, db, (size_t) Ec, 0u, end_bit, s), "sort size");
+        PRC_ALLOC(tmp, tb);
+        PRC_TRY(rocprim::radix_sort_keys((void*) tmp.p, tb, db, (size_t) Ec, 0u, end_bit, s), "sort");
+        PRC_TRY(hipStreamSynchronize(s), "sort sync");
+        sk = db.current();
+        if (sk == k1.p) k2.release(); else k1.release();
+    }
+    // ---- cells and natural pairs ----
+    PRC_ALLOC(cflag, Ec + 1);
+    PRC_ALLOC(incl, Ec + 1);
+    PRC_ALLOC(nat, Ec + 1);
+    PRC_ALLOC(natpre, Ec + 1);
+    hipLaunchKernelGGL(prc_flag_kernel, dim3(prc_grid_for(Ec + 1)), dim3(256), 0, s, sk, Ec, cflag.p, nat.p);
+    {
+        size_t tb = 0;
+        PRC_TRY(rocprim::inclusive_scan(nullptr, tb, cflag.p, incl.p, (size_t) Ec, rocprim::plus<int32_t>(), s), "scan size");
+        if (tmp.n < tb) { tmp.release(); PRC_ALLOC(tmp, tb); }
+        PRC_TRY(rocprim::inclusive_scan((void*) tmp.p, tb, cflag.p, incl.p, (size_t) Ec, rocprim::plus<int32_t>(), s), "scan");
+        PRC_TRY(prc_exscan(nat.p, natpre.p, Ec + 1, tmp, s), "scan");
+        int32_t last = 0;
+        PRC_TRY(hipMemcpyAsync(&last, incl.p + (Ec - 1), 4, hipMemcpyDeviceToHost, s), "copy");
+        PRC_TRY(hipStreamSynchronize(s), "sync");
+        c->ncells = nc = last;
+    }
+    PRC_ALLOC(first, nc + 1);
+    PRC_ALLOC(ckey, nc + 1);
+    PRC_ALLOC(groups, nc + 1);
+    PRC_ALLOC(c1raw, nc + 1);
+    PRC_ALLOC(c1, nc + 1);
+    PRC_ALLOC(ttab, 4 * (c->ntiles + 1));
+    PRC_ALLOC(delta, c->ntiles + 1);
+    PRC_ALLOC(mode, c->ntiles + 1);
+    hipLaunchKernelGGL(prc_cell_first_kernel, dim3(prc_grid_for(Ec + 1)), dim3(256), 0, s, sk, (const int32_t*) cflag.p,
+                       (const int32_t*) incl.p, Ec, nc, first.p, ckey.p);
+    hipLaunchKernelGGL(prc_cell_groups_kernel, dim3(prc_grid_for(nc + 1)), dim3(256), 0, s, (const int32_t*) first.p,
+                       (const int32_t*) nullptr, nc, groups.p, (int32_t*) nullptr);
+    PRC_TRY(prc_exscan(groups.p, c1raw.p, nc + 1, tmp, s), "scan");
+    hipLaunchKernelGGL(prc_tile_table_kernel, dim3(prc_grid_for(c->ntiles + 1)), dim3(256), 0, s, (const uint32_t*) ckey.p, nc,
+                       binbits, c->ntiles, (const int32_t*) c1raw.p, (const int32_t*) natpre.p, (const int32_t*) first.p, ttab.p);
+    ht.resize((size_t) 4 * (c->ntiles + 1));
+    PRC_TRY(hipMemcpyAsync(ht.data(), ttab.p, sizeof(int32_t) * ht.size(), hipMemcpyDeviceToHost, s), "copy");
+    PRC_TRY(hipStreamSynchronize(s), "sync");
+    // ---- per tile: form (pair / edge) and start (on a block boundary) ----
+    hdelta.assign((size_t) c->ntiles + 1, 0);
+    tstart.assign((size_t) c->ntiles + 1, 0);
+    hmode.assign((size_t) c->ntiles + 1, 0);
+    for (int64_t t = 0; t < c->ntiles; t++) {
+        const int64_t g = (int64_t) ht[4 * (t + 1) + 1] - ht[4 * t + 1], np = (int64_t) ht[4 * (t + 1) + 2] - ht[4 * t + 2],
+                      ne = (int64_t) ht[4 * (t + 1) + 3] - ht[4 * t + 3];
+        hmode[t] = (np > 0 && (double) ne >= pair_min * (double) np) ? 1 : 0;
+        if (hmode[t]) { pair_edges += ne; pair_tiles++; }
+        hdelta[t] = tstart[t] - ht[4 * t + 1];
+        tstart[t + 1] = tstart[t] + (int32_t) ((g + PRC_BLK_GROUPS - 1) / PRC_BLK_GROUPS * PRC_BLK_GROUPS);
+    }
+    ngroups1 = tstart[c->ntiles];
+    if (ngroups1 * PRC_G >= (1LL << 31)) {
+        gmx_set_error("pr cold: %lld padded entries exceed int32", (long long) (ngroups1 * PRC_G));
+        st = GMX_ERR_ARG;
+        goto done;
+    }
+    c->P1 = ngroups1 * PRC_G;
+    PRC_TRY(hipMemcpyAsync(delta.p, hdelta.data(), sizeof(int32_t) * hdelta.size(), hipMemcpyHostToDevice, s), "copy");
+    PRC_TRY(hipMemcpyAsync(mode.p, hmode.data(), hmode.size(), hipMemcpyHostToDevice, s), "copy");
+    hipLaunchKernelGGL(prc_cell_start_kernel, dim3(prc_grid_for(nc)), dim3(256), 0, s, (const int32_t*) c1raw.p,
+                       (const uint32_t*) ckey.p, binbits, (const int32_t*) delta.p, nc, c1.p);
+    // ---- final pair ends, items per cell, bin-major order ----
+    hipLaunchKernelGGL(prc_final_flag_kernel, dim3(prc_grid_for(Ec)), dim3(256), 0, s, (const int32_t*) incl.p,
+                       (const int32_t*) first.p, (const int32_t*) c1.p, (const uint32_t*) ckey.p, binbits,
+                       (const uint8_t*) mode.p, Ec, nat.p);
+    PRC_TRY(prc_exscan(nat.p, natpre.p, Ec + 1, tmp, s), "scan");   // natpre: pair ends before an edge
+    PRC_ALLOC(counts, nc + 1);
+    PRC_ALLOC(key2, nc);
+    PRC_ALLOC(key2s, nc);
+    PRC_ALLOC(id, nc);
+    PRC_ALLOC(order2, nc);
+    PRC_ALLOC(groups2, nc + 1);
+    PRC_ALLOC(c2s, nc + 1);
+    PRC_ALLOC(c2, nc);
+    hipLaunchKernelGGL(prc_cell_groups_kernel, dim3(prc_grid_for(nc + 1)), dim3(256), 0, s, (const int32_t*) first.p,
+                       (const int32_t*) natpre.p, nc, groups.p, counts.p);
+    hipLaunchKernelGGL(prc_cell_key2_kernel, dim3(prc_grid_for(nc)), dim3(256), 0, s, (const uint32_t*) ckey.p, nc, binbits,
+                       tilebits, key2.p, id.p);
+    {
+        size_t tb = 0;
+        PRC_TRY(rocprim::radix_sort_pairs(nullptr, tb, key2.p, key2s.p, id.p, order2.p, (size_t) nc, 0u, (unsigned) (binbits + tilebits), s), "sort size");
+        if (tmp.n < tb) { tmp.release(); PRC_ALLOC(tmp, tb); }
+        PRC_TRY(rocprim::radix_sort_pairs((void*) tmp.p, tb, key2.p, key2s.p, id.p, order2.p, (size_t) nc, 0u, (unsigned) (binbits + tilebits), s), "sort");
+    }
+    PRC_TRY(hipMemsetAsync(groups2.p + nc, 0, sizeof(int32_t), s), "memset");
+    hipLaunchKernelGGL(prc_gather_i32_kernel, dim3(prc_grid_for(nc)), dim3(256), 0, s, (const int32_t*) groups.p,
+                       (const int32_t*) order2.p, nc, groups2.p);
+    PRC_TRY(prc_exscan(groups2.p, c2s.p, nc + 1, tmp, s), "scan");
+    hipLaunchKernelGGL(prc_scatter_i32_kernel, dim3(prc_grid_for(nc)), dim3(256), 0, s, (const int32_t*) c2s.p,
+                       (const int32_t*) order2.p, nc, c2.p);
+    {
+        int32_t tot = 0, np = 0;
+        PRC_TRY(hipMemcpyAsync(&tot, c2s.p + nc, 4, hipMemcpyDeviceToHost, s), "copy");
+        PRC_TRY(hipMemcpyAsync(&np, natpre.p + Ec, 4, hipMemcpyDeviceToHost, s), "copy");
+        PRC_TRY(hipStreamSynchronize(s), "sync");
+        ngroups2 = tot;
+        c->npairs = np;
+    }
+    if (ngroups2 * PRC_G >= (1LL << 31)) {
+        gmx_set_error("pr cold: %lld padded items exceed int32", (long long) (ngroups2 * PRC_G));
+        st = GMX_ERR_ARG;
+        goto done;
+    }
+    c->P2 = ngroups2 * PRC_G;
+    // ---- the two streams ----
+    PRC_ALLOC(c->srcl, c->P1);
+    PRC_ALLOC(c->ob, ngroups1);
+    PRC_ALLOC(c->rowl, c->P2);
+    PRC_ALLOC(c->val, (size_t) c->P2 * prm.elem);
+    hipLaunchKernelGGL(prc_fill_u16_kernel, dim3(prc_grid_for(c->P1)), dim3(256), 0, s, c->srcl.p, c->P1, (uint16_t) tile_src);
+    PRC_TRY(hipMemsetAsync(c->rowl.p, 0xff, (size_t) c->P2 * 2, s), "memset");
+    PRC_TRY(hipMemsetAsync(c->val.p, 0, (size_t) c->P2 * prm.elem, s), "memset");
+    hipLaunchKernelGGL(prc_fill_items_kernel, dim3(prc_grid_for(Ec)), dim3(256), 0, s, sk, (const int32_t*) incl.p,
+                       (const int32_t*) first.p, (const int32_t*) c1.p, (const int32_t*) c2.p, (const int32_t*) nat.p,
+                       (const int32_t*) natpre.p, Ec, c->srcl.p, c->rowl.p);
+    hipLaunchKernelGGL(prc_fill_ob_kernel, dim3(prc_grid_for(ngroups1)), dim3(256), 0, s, (const int32_t*) c1.p,
+                       (const int32_t*) c2.p, (const int32_t*) first.p, (const int32_t*) natpre.p, nc, ngroups1, c->ob.p);
+    PRC_ALLOC(tab2, c->nbins + 1);
+    hipLaunchKernelGGL(prc_bin_table_kernel, dim3(prc_grid_for(c->nbins + 1)), dim3(256), 0, s, (const uint32_t*) key2s.p,
+                       (const int32_t*) c2s.p, nc, tilebits, ngroups2, c->nbins, tab2.p);
+    h2.resize((size_t) c->nbins + 1);
+    PRC_TRY(hipMemcpyAsync(h2.data(), tab2.p, sizeof(int32_t) * h2.size(), hipMemcpyDeviceToHost, s), "copy");
+    PRC_TRY(hipStreamSynchronize(s), "sync");
+    {   // an accumulator never receives more terms than its bin has items: that bound sizes the second limb
+        int64_t biggest = 1;
+        for (int64_t b = 0; b < c->nbins; b++) biggest = std::max<int64_t>(biggest, ((int64_t) h2[b + 1] - h2[b]) * PRC_G);
+        // every term of the second limb is < 2^lo_bits; `biggest` of them must stay below 2^63
+        c->lo_bits = 62 - gmx_bits_for(biggest + 1);
+        if (c->lo_bits > 62) c->lo_bits = 62;
+        if (c->lo_bits < 20) c->lo_bits = 20;
+    }
+    // ---- work lists ----
+    {
+        const int ch1 = std::max(PRC_BLK_GROUPS, prc_env_int("GMX_PR_COLD_CHUNK1", 8192)) / PRC_BLK_GROUPS * PRC_BLK_GROUPS;   // groups per phase-1 item
+        const int ch2 = std::max(8, prc_env_int("GMX_PR_COLD_CHUNK", 4096)) / 8 * 8;    // groups per phase-2 item (128 K items)
+        for (int64_t t = 0; t < c->ntiles; t++) {
+            const int32_t g0 = tstart[t];
+            // pair tiles run whole blocks (the padding behind the last cell ends no pair); edge tiles stop at the
+            // last real group (an entry there would be stored)
+            const int32_t g1 = hmode[t] ? tstart[t + 1] : g0 + (ht[4 * (t + 1) + 1] - ht[4 * t + 1]);
+            for (int32_t g = g0; g < g1; g += ch1) (hmode[t] ? v1p : v1e).push_back({(int32_t) t, g, std::min(g1, g + ch1), 0});
+        }
+        int32_t slot = 0;
+        for (int64_t b = 0; b < c->nbins; b++) {
+            const int32_t g0 = h2[b], g1 = h2[b + 1];
+            if (g1 <= g0) continue;
+            if (g1 - g0 <= ch2) { v2.push_back({(int32_t) b, g0, g1, -1}); continue; }
+            const int32_t s0 = slot;
+            for (int32_t g = g0; g < g1; g += ch2) v2.push_back({(int32_t) b, g, std::min(g1, g + ch2), slot++});
+            v3.push_back({(int32_t) b, s0, slot - s0, 0});
+        }
+        // big items first: the queue then balances the tail with small ones
+        auto by_size1 = [](const prc_item1& a, const prc_item1& b) { return a.g1 - a.g0 > b.g1 - b.g0; };
+        std::stable_sort(v1p.begin(), v1p.end(), by_size1);
+        std::stable_sort(v1e.begin(), v1e.end(), by_size1);
+        std::stable_sort(v2.begin(), v2.end(), [](const prc_item2& a, const prc_item2& b) { return a.g1 - a.g0 > b.g1 - b.g0; });
+        c->n1p = (int64_t) v1p.size();
+        c->n1e = (int64_t) v1e.size();
+        c->n2 = (int64_t) v2.size();
+        c->n3 = (int64_t) v3.size();
+        c->nslots = slot;
+        PRC_ALLOC(c->it1p, std::max<size_t>(1, v1p.size()));
+        PRC_ALLOC(c->it1e, std::max<size_t>(1, v1e.size()));
+        PRC_ALLOC(c->it2, std::max<size_t>(1, v2.size()));
+        PRC_ALLOC(c->it3, std::max<size_t>(1, v3.size()));
+        PRC_ALLOC(c->scratch, std::max<size_t>(1, (size_t) slot * c->limbs * c->binrows));
+        if (!v1p.empty()) PRC_TRY(hipMemcpy(c->it1p.p, v1p.data(), sizeof(prc_item1) * v1p.size(), hipMemcpyHostToDevice), "copy");
+        if (!v1e.empty()) PRC_TRY(hipMemcpy(c->it1e.p, v1e.data(), sizeof(prc_item1) * v1e.size(), hipMemcpyHostToDevice), "copy");
+        if (!v2.empty()) PRC_TRY(hipMemcpy(c->it2.p, v2.data(), sizeof(prc_item2) * v2.size(), hipMemcpyHostToDevice), "copy");
+        if (!v3.empty()) PRC_TRY(hipMemcpy(c->it3.p, v3.data(), sizeof(prc_item3) * v3.size(), hipMemcpyHostToDevice), "copy");
+    }
+    PRC_TRY(hipStreamSynchronize(s), "sync");
+    if (getenv("GMX_PR_DEBUG"))
+        fprintf(stderr, "gmx pr cold: T %lld, %lld edges -> %lld entries in %lld cells (%lld tiles x %lld bins); %lld pair tiles with %lld edges; "
+                "%lld pairs -> %lld items; work items %lld + %lld / %lld / %lld, %lld slots, lo_bits %d\n", (long long) prm.T, (long long) Ec,
+                (long long) c->P1, (long long) nc, (long long) c->ntiles, (long long) c->nbins, (long long) pair_tiles, (long long) pair_edges,
+                (long long) c->npairs, (long long) c->P2, (long long) c->n1p, (long long) c->n1e, (long long) c->n2, (long long) c->n3,
+                (long long) c->nslots, c->lo_bits);
+done:
+    if (st != GMX_OK) {
+        delete c;
+        return st;
+    }
+    *outp = c;
+    return GMX_OK;
+}
+
+void pr_cold_free(pr_cold* c) { delete c; }
+
+const void* pr_cold_partial(const pr_cold* c) { return c ? (const void*) c->cold.p : nullptr; }
+int64_t pr_cold_edges(const pr_cold* c) { return c ? c->Ec : 0; }
+int64_t pr_cold_items(const pr_cold* c) { return c ? c->P2 : 0; }
+
+template <typename S>
+static void prc_launch(pr_cold* c, const void* contrib, hipStream_t s) {
+    constexpr int TILE = PRC_LDS_BYTES / (int) sizeof(S);
+    constexpr int LIMBS = sizeof(S) == 4 ? 1 : 2;
+    constexpr int BINROWS = PRC_LDS_BYTES / 8 / LIMBS;
+    const double lo_scale = ldexp(1.0, c->lo_bits);
+    const int64_t span = c->prm.slice - c->prm.T;
+    (void) hipMemsetAsync(c->queue.p, 0, 3 * 64 * sizeof(unsigned int), s);
+    if (c->n1p > 0)
+        hipLaunchKernelGGL((pr_cold_pair_kernel<S, TILE>), dim3((unsigned) std::min<int64_t>(c->grid, c->n1p)), dim3(PRC_THREADS), 0, s,
+                           (const prc_item1*) c->it1p.p, (int) c->n1p, c->queue.p, (const S*) contrib, c->ncold, span, c->prm.slice,
+                           c->prm.T, (const uint16_t*) c->srcl.p, (const int32_t*) c->ob.p, (S*) c->val.p);
+    if (c->n1e > 0)
+        hipLaunchKernelGGL((pr_cold_gather_kernel<S, TILE>), dim3((unsigned) std::min<int64_t>(c->grid, c->n1e)), dim3(PRC_THREADS), 0, s,
+                           (const prc_item1*) c->it1e.p, (int) c->n1e, c->queue.p, (const S*) contrib, c->ncold, span, c->prm.slice,
+                           c->prm.T, (const uint16_t*) c->srcl.p, (const int32_t*) c->ob.p, (S*) c->val.p);
+    hipLaunchKernelGGL((pr_cold_accum_kernel<S, BINROWS, LIMBS>), dim3((unsigned) std::min<int64_t>(c->grid, c->n2)), dim3(PRC_THREADS), 0, s,
+                       (const prc_item2*) c->it2.p, (int) c->n2, c->queue.p, (const uint16_t*) c->rowl.p, (const S*) c->val.p,
+                       c->prm.nactive, lo_scale, (S*) c->cold.p, c->scratch.p);
+    if (c->n3 > 0)
+        hipLaunchKernelGGL((pr_cold_reduce_kernel<S, BINROWS, LIMBS>), dim3(BINROWS / 64, (unsigned) c->n3), dim3(1024), 0, s,
+                           (const prc_item3*) c->it3.p, c->prm.nactive, lo_scale, (const unsigned long long*) c->scratch.p, (S*) c->cold.p);
+}
+
+int pr_cold_launch(pr_cold* c, const void* contrib, hipStream_t s) {
+    if (!c || c->Ec == 0 || c->n2 == 0) return GMX_OK;
+    if (c->prm.elem == 4) prc_launch<float>(c, contrib, s);
+    else prc_launch<double>(c, contrib, s);
+    return GMX_OK;
+}

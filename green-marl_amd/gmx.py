@@ -17,6 +17,7 @@ GMX_GRAPH_NO_REVERSE = 0x2
 GMX_PR_RELABEL = 0x1
 GMX_PR_HOT_LDS = 0x2
 GMX_PR_SLICED = 0x4
+GMX_PR_COLD_PB = 0x8
 INT_MAX = 2147483647
 
 
@@ -51,7 +52,7 @@ EXPORTS = [
     "gmx_pr_set_chunks", "gmx_pr_num_chunks", "gmx_pr_chunk_range", "gmx_pr_step_chunk", "gmx_pr_contrib_next_full",
     "gmx_ipc_export", "gmx_ipc_open", "gmx_ipc_close", "gmx_pr_contrib_buffers", "gmx_pr_set_peers",
     "gmx_pr_push_chunk", "gmx_pr_push_current", "gmx_pr_push_join",
-    "gmx_pr_timing", "gmx_pr_kernel_time", "gmx_pr_kernel_name", "gmx_pr_default_options",
+    "gmx_pr_timing", "gmx_pr_kernel_time", "gmx_pr_kernel_name", "gmx_pr_default_options", "gmx_pr_cold_info",
 ]
 
 _LIB = None
@@ -128,6 +129,7 @@ def lib():
         L.gmx_pr_diff.argtypes = [vp, vp, C.POINTER(C.c_double)]
         L.gmx_pr_download.argtypes = [vp, vp]
         L.gmx_pr_work.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+        L.gmx_pr_cold_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
         L.gmx_pr_default_options.argtypes = [i64, C.c_int]
         L.gmx_pr_default_options.restype = C.c_uint32
         L.gmx_pr_timing.argtypes = [vp, C.c_int]
@@ -489,6 +491,12 @@ class PageRankState:
 
     def kernel_name(self):
         return lib().gmx_pr_kernel_name(self._h).decode()
+
+    def cold_info(self):
+        """(hot ids per rank range, binned edges, items of phase 2) of the binned part; hot_ids = -1 without one."""
+        t, e, p = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _ck(lib().gmx_pr_cold_info(self._h, C.byref(t), C.byref(e), C.byref(p)))
+        return {"hot_ids": t.value, "cold_edges": e.value, "padded_items": p.value}
 
     def work(self):
         e, r, b = C.c_int64(0), C.c_int64(0), C.c_int64(0)

@@ -169,6 +169,9 @@ int gmx_triangle_counting_part(gmx_graph_t* g, int part, int nparts, int64_t* co
 #define GMX_PR_RELABEL   0x1u   /* degree-sorted internal numbering (default on in whole-kernel entries) */
 #define GMX_PR_HOT_LDS   0x2u   /* keep the hottest contributions in LDS */
 #define GMX_PR_SLICED    0x4u   /* split in-edges by source slice, one slice per XCD L2 (needs GMX_PR_RELABEL) */
+#define GMX_PR_COLD_PB   0x8u   /* with GMX_PR_SLICED: edges from the cold sources (the tail of the degree order, past what the
+                                   L2s hold; GMX_PR_COLD=<hot ids per rank range> overrides the size rule) leave the pull
+                                   sweep and go through plan-time-ordered destination bins: no 128-byte line per gather */
 /* The option set the whole-kernel entries use for a graph of V vertices on nranks ranks. */
 uint32_t gmx_pr_default_options(int64_t V, int nranks);
 int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nranks, uint32_t options, gmx_pr_t** out);
@@ -232,6 +235,9 @@ int gmx_pr_kernel_time(gmx_pr_t* p, int32_t* launches, double* mean_ms);
 const char* gmx_pr_kernel_name(gmx_pr_t* p);
 /* Algorithmic bytes / edges one step of this rank processes. */
 int gmx_pr_work(gmx_pr_t* p, int64_t* edges, int64_t* rows, int64_t* algorithmic_bytes);
+/* The binned part of the plan (GMX_PR_COLD_PB): hot ids per rank range (-1 = no binned part, 0 = every edge is
+ * binned), edges taken out of the pull sweep, and the items ((tile, row) pair sums + cell padding) phase 2 streams. */
+int gmx_pr_cold_info(gmx_pr_t* p, int64_t* hot_ids, int64_t* cold_edges, int64_t* padded_items);
 
 #ifdef __cplusplus
 }

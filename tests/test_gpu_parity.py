@@ -287,6 +287,71 @@ def test_pagerank_row_chunked_steps(gmx, scale, nranks, chunks, elem):
     g.free()
 
 
+@pytest.mark.parametrize("scale,nranks,chunks,elem,hot,chunk2", [
+    (18, 1, 1, 4, 16384, 0), (18, 1, 1, 8, 16384, 0), (18, 1, 2, 4, 32768, 8), (18, 1, 1, 8, 16384, 16),
+    (18, 4, 1, 8, 16384, 0), (19, 2, 3, 4, 49152, 64), (18, 3, 2, 8, 16384, 8), (17, 1, 1, 4, 16384, 8),
+    (18, 1, 1, 4, 0, 0), (18, 1, 2, 8, 0, 8), (16, 2, 1, 8, 0, 0), (19, 4, 2, 4, 0, 16), (14, 1, 1, 4, 0, 0)])
+def test_pagerank_cold_sources_binned(gmx, scale, nranks, chunks, elem, hot, chunk2, monkeypatch):
+    """GMX_PR_COLD_PB: the in-edges whose source lies past the hot prefix of its rank range leave the pull sweep
+    and are summed by the two binned phases (tile-major gather from LDS, bin-major fixed-point accumulation in
+    LDS, chunk reduction for split bins).  Small graphs take the path through GMX_PR_COLD (hot ids per rank
+    range) and GMX_PR_COLD_CHUNK (groups per phase-2 item, to split bins); rank ranges smaller than an LDS tile
+    make tiles straddle rank ranges.  Ranks equal the oracle's, and two runs are bit-identical."""
+    import torch
+    monkeypatch.setenv("GMX_PR_COLD", str(hot))
+    if chunk2:
+        monkeypatch.setenv("GMX_PR_COLD_CHUNK", str(chunk2))
+    og = po.rmat_graph(scale, permute=True)
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    iters = 6
+    want, it, want_diff = po.pagerank(og, 1e-300, 0.85, iters)
+    options = gmx.GMX_PR_RELABEL | gmx.GMX_PR_HOT_LDS | gmx.GMX_PR_SLICED | gmx.GMX_PR_COLD_PB
+    states = [gmx.PageRankState(g, elem, r, nranks, options) for r in range(nranks)]
+    info = [s.cold_info() for s in states]
+    assert all(i["hot_ids"] == hot and i["cold_edges"] > 0 and i["padded_items"] > 0 for i in info), info
+    if hot == 0:
+        assert sum(i["cold_edges"] for i in info) == og.M   # no edge is left to the pull sweep
+    assert sum(s.work()["edges"] for s in states) == og.M
+    for s in states:
+        assert s.set_chunks(chunks) == chunks
+    ranges = [states[0].chunk_range(c) for c in range(chunks)]
+    need = states[0].exchange_count()
+    n = torch.as_tensor(states[0].contrib_slice(), device="cuda").numel()
+
+    def run():
+        for s in states:
+            s.reset(0.85)
+        fulls = [torch.as_tensor(s.contrib_full(), device="cuda") for s in states]
+        for dst in fulls:
+            for r, src in enumerate(fulls):
+                if dst is not src:
+                    dst[r * n:r * n + need].copy_(src[r * n:r * n + need])
+        torch.cuda.synchronize()
+        for _ in range(iters):
+            nxt = [torch.as_tensor(s.contrib_next_full(), device="cuda") for s in states]
+            for c, (off, cnt) in enumerate(ranges):
+                for s in states:
+                    s.step_chunk(c)
+                for dst in nxt:
+                    for r, src in enumerate(nxt):
+                        if dst is not src:
+                            dst[r * n + off:r * n + off + cnt].copy_(src[r * n + off:r * n + off + cnt])
+            torch.cuda.synchronize()
+        out = np.zeros(og.N, dtype=np.float64 if elem == 8 else np.float32)
+        for s in states:
+            s.download(out)
+        return out, sum(s.diff() for s in states)
+
+    out, diff = run()
+    assert rel_err(out, want) < (PR_RTOL_F64 if elem == 8 else PR_RTOL_F32)
+    assert abs(diff - want_diff) <= (1e-9 if elem == 8 else 1e-3) * max(want_diff, 1e-30) + 1e-15
+    out2, diff2 = run()
+    assert np.array_equal(out, out2) and diff == diff2          # integer accumulation: run-to-run bit-identical
+    for s in states:
+        s.free()
+    g.free()
+
+
 @pytest.mark.parametrize("world,chunks,elem", [(3, 2, 8), (2, 1, 4)])
 def test_peer_push_exchange_between_processes(gmx, world, chunks, elem):
     """The N > 1 exchange by direct copies into the peers' hipIpc-mapped replicas, with real processes (one
