@@ -115,8 +115,19 @@ struct pr_cold_params {
 // keys[Ec]: (row << 32 | source) of the cold in-edges of the owned rows, any order (device).
 int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, hipStream_t s, pr_cold** out);
 void pr_cold_free(pr_cold* c);
-// enqueue phases 1-3: reads the contribution replica, leaves the cold row sums in pr_cold_partial()
-int pr_cold_launch(pr_cold* c, const void* contrib, hipStream_t s);
+// what the fused finish needs to apply the PageRank update of active row i itself (see pr_combine_kernel)
+struct pr_cold_fuse {
+    const int32_t* active;     // [nactive] local row of active row i
+    const int32_t* outdeg_c;   // [nactive]
+    void* rk_c;                // [nactive] x elem: ranks, updated in place
+    void* next_owned;          // owned range of the replica being produced, indexed by local row
+    double base, d;
+};
+// enqueue phases 1-3: reads the contribution replica; fuse == NULL leaves the row sums in pr_cold_partial(),
+// otherwise the rows are finished in place and pr_cold_diff_partials() holds the |val - rank| partials
+int pr_cold_launch(pr_cold* c, const void* contrib, const pr_cold_fuse* fuse, hipStream_t s);
+const double* pr_cold_diff_partials(const pr_cold* c, int64_t* n);
+bool pr_cold_covers_all_rows(const pr_cold* c);
 const void* pr_cold_partial(const pr_cold* c);   // [nactive] x elem, indexed like the per-slice partial sums
 int64_t pr_cold_edges(const pr_cold* c);
 int64_t pr_cold_items(const pr_cold* c);

@@ -1060,6 +1060,21 @@ __global__ void pr_diff_reduce_kernel(const double* __restrict__ part, int64_t g
     }
 }
 
+// the same for two arrays one after the other (fixed order)
+__global__ void pr_diff_reduce2_kernel(const double* __restrict__ a, int64_t na, const double* __restrict__ b, int64_t nb, double* __restrict__ out) {
+    __shared__ double s[1024 / 64];
+    double t = 0.0;
+    for (int64_t i = threadIdx.x; i < na + nb; i += blockDim.x) t += i < na ? a[i] : b[i - na];
+    t = wave_sum(t);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0;
+        for (int w = 0; w < (int) (blockDim.x >> 6); w++) r += s[w];
+        *out = r;
+    }
+}
+
 template <typename S>
 __global__ void pr_reset_kernel(int64_t rows, double N, const int32_t* __restrict__ outdeg,
                                 S* __restrict__ rk, S* __restrict__ contrib_owned) {
@@ -1525,8 +1540,26 @@ static void launch_sliced_chunk(gmx_pr* p, int c, hipStream_t s) {
     const int j = C - 1 - c;
     S* next_owned = (S*) p->contrib[1 - p->cur].p + p->row_lo;
     pr_sliced_args a = p->sl;
-    // the cold sources' row sums of ALL rows, once per step, before the first chunk is combined
-    if (c == 0 && p->cold) (void) pr_cold_launch(p->cold, p->contrib[p->cur].p, s);
+    if (p->cold && p->Eh == 0 && C == 1 && pr_cold_covers_all_rows(p->cold)) {
+        // every edge is binned and the step is one piece: the binned phases finish the rows themselves (no
+        // partial-sum array, no combine pass)
+        const pr_cold_fuse fz{(const int32_t*) p->sl_active.p, (const int32_t*) p->sl_outdeg_c.p, (void*) p->sl_rk_c.p, (void*) next_owned, base, p->d};
+        (void) pr_cold_launch(p->cold, p->contrib[p->cur].p, &fz, s);
+        double* dfirst = p->diff_part.p + PR_COMBINE_GRID;
+        if (p->cnt == 0) {   // first sweep after a reset: settle the rows without in-edges once
+            hipLaunchKernelGGL(pr_inactive_first_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, (const uint8_t*) p->sl_is_active.p,
+                               (int64_t) 0, p->rows, p->outdeg.p, (S*) p->rk.p, next_owned, base, p->d, dfirst);
+            hipLaunchKernelGGL(pr_inactive_copy_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, (const uint8_t*) p->sl_is_active.p,
+                               p->rows, (S*) p->contrib[p->cur].p + p->row_lo, (const S*) next_owned);
+        }
+        int64_t nd = 0;
+        const double* dp = pr_cold_diff_partials(p->cold, &nd);
+        hipLaunchKernelGGL(pr_diff_reduce2_kernel, dim3(1), dim3(1024), 0, s, dp, nd, (const double*) dfirst,
+                           (int64_t) (p->cnt == 0 ? PR_COMBINE_GRID : 0), p->diff.p);
+        return;
+    }
+    // the binned sources' row sums of ALL rows, once per step, before the first chunk is combined
+    if (c == 0 && p->cold) (void) pr_cold_launch(p->cold, p->contrib[p->cur].p, nullptr, s);
     int64_t maxfix = 0, total_blk = 0;
     for (int q = 0; q < p->ns; q++) {
         pr_slice_desc& sd = a.s[q];
@@ -1868,8 +1901,10 @@ extern "C" int gmx_pr_kernel_time(gmx_pr_t* p, int32_t* launches, double* mean_m
 
 extern "C" const char* gmx_pr_kernel_name(gmx_pr_t* p) {
     if (!p) return "";
+    if (p->ns > 0 && p->cold && p->Eh == 0)
+        return "pr_cold_pair_kernel+pr_cold_gather_kernel+pr_cold_accum_kernel+pr_cold_reduce_kernel+pr_diff_reduce2_kernel (+pr_combine_kernel when a step is enqueued in row chunks)";
     if (p->ns > 0 && p->cold)
-        return "pr_cold_gather_kernel+pr_cold_accum_kernel+pr_cold_reduce_kernel+pr_wave_sliced_kernel+pr_sliced_fixup_kernel+pr_combine_kernel+pr_diff_reduce_kernel";
+        return "pr_cold_pair_kernel+pr_cold_gather_kernel+pr_cold_accum_kernel+pr_cold_reduce_kernel+pr_wave_sliced_kernel+pr_sliced_fixup_kernel+pr_combine_kernel+pr_diff_reduce_kernel";
     if (p->ns > 0) return "pr_wave_sliced_kernel+pr_sliced_fixup_kernel+pr_combine_kernel+pr_diff_reduce_kernel";
     return "pr_wave_kernel+pr_fixup_kernel+pr_diff_reduce_kernel";
 }

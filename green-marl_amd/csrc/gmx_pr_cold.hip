@@ -42,7 +42,11 @@
 
 #define PRC_G 32                 // edges / items per group (a cell is padded to whole groups)
 #define PRC_BLK_GROUPS 16        // groups per wave block of the pair kernel (512 edges); tiles start on block boundaries
-#define PRC_LDS_BYTES 131072     // contribution tile / accumulator array
+#define PRC_LDS_BYTES 131072     // accumulator array of phase 2
+#define PRC_STAGE_BYTES 2048     // per wave: pair sums of a block on their way to coalesced stores
+#define PRC_LDS_LIMIT 163840     // LDS of a CU
+// elements of the contribution tile of phase 1: what the 16 stages (+ a dummy slot per lane) and a few words leave
+static constexpr int prc_tile_elems(int elem) { return (PRC_LDS_LIMIT - 16 * (PRC_STAGE_BYTES + 64 * elem) - 64) / elem; }
 #define PRC_THREADS 1024
 #define PRC_WAVES (PRC_THREADS / 64)
 #define PRC_UNROLL 4             // pieces (8 groups = 256 items) a wave keeps in flight
@@ -71,12 +75,15 @@ struct pr_cold {
     dbuf<char> val;          // [P2] x elem, bin-major: written by phase 1, read by phase 2
     dbuf<char> cold;         // [nactive] x elem
     dbuf<prc_item1> it1p, it1e;
+    dbuf<int32_t> torg;      // [2 * ntiles] rank range and offset behind the hot/cold border where a tile starts
     dbuf<prc_item2> it2;
     dbuf<prc_item3> it3;
     int64_t n1p = 0, n1e = 0, n2 = 0, n3 = 0, nslots = 0;
     dbuf<unsigned long long> scratch;   // [nslots][limbs][binrows]
     dbuf<unsigned int> queue;           // [3 * 64]
+    dbuf<double> diffp;                 // fused finish: [n2] partials of phase 2, then [n3 * binrows / 64] of phase 3
     int grid = 256;
+    bool all_bins = false;   // every bin has items (the fused finish reaches every active row)
 };
 
 static int prc_grid_for(int64_t n, int block = 256) {
@@ -279,20 +286,27 @@ template <typename S> struct prc_vec4;
 template <> struct prc_vec4<float> { typedef prc_f32x4 type; };
 template <> struct prc_vec4<double> { typedef prc_f64x4 type; };
 
-__device__ __forceinline__ int64_t prc_id_of(int64_t cp, int64_t span, int64_t slice, int64_t T) {
-    return (cp / span) * slice + T + cp % span;
-}
-
-// contribution tile `tile` (TILE - 1 sources) -> LDS; the last slot is the zero that padding entries read
+// contribution tile `tile` (TILE - 1 sources) -> LDS; the last slot is the zero that padding entries read.  The
+// tile's sources are consecutive ids inside a rank range and continue at the hot/cold border of the next range; the
+// plan stores where each tile starts (org[2 * tile] = rank range, org[2 * tile + 1] = offset behind the border), so
+// the copy is a few contiguous pieces with all loads of a piece in flight together.
 template <typename S, int TILE>
-__device__ __forceinline__ void prc_load_tile(S* __restrict__ s_tile, int tile, const S* __restrict__ contrib,
-                                              int64_t ncold, int64_t span, int64_t slice, int64_t T) {
-    const int64_t cp0 = (int64_t) tile * (TILE - 1);
-#pragma unroll 4
-    for (int i = threadIdx.x; i < TILE; i += PRC_THREADS) {
-        const int64_t cp = cp0 + i;
-        s_tile[i] = (i < TILE - 1 && cp < ncold) ? __builtin_nontemporal_load(contrib + prc_id_of(cp, span, slice, T)) : (S) 0;
+__device__ __forceinline__ void prc_load_tile(S* __restrict__ s_tile, int tile, const int32_t* __restrict__ org,
+                                              const S* __restrict__ contrib, int nranks, int64_t span, int64_t slice, int64_t T) {
+    int r = org[2 * tile];
+    int64_t l = org[2 * tile + 1];
+    int i0 = 0;
+    while (i0 < TILE - 1 && r < nranks) {   // (workgroup-uniform)
+        const int64_t left = span - l;
+        const int n = left < TILE - 1 - i0 ? (int) left : TILE - 1 - i0;
+        const S* __restrict__ src = contrib + ((int64_t) r * slice + T + l);
+#pragma unroll 8
+        for (int j = threadIdx.x; j < n; j += PRC_THREADS) s_tile[i0 + j] = __builtin_nontemporal_load(src + j);
+        i0 += n;
+        r++;
+        l = 0;
     }
+    for (int j = i0 + threadIdx.x; j < TILE; j += PRC_THREADS) s_tile[j] = (S) 0;
 }
 
 // wave-level data movement on the VALU (DPP): no LDS traffic next to the tile gathers
@@ -318,28 +332,40 @@ __device__ __forceinline__ void prc_seg_step(double& v, int& f) {
     f |= fo;
 }
 
-// one block of the pair form: 8 entries of this lane in `cur`, `o` = slot of the first pair that ends in the lane's group
+// clears a double where mask is all ones (mask is 0 or -1): two bit operations, no compare
+__device__ __forceinline__ double prc_clear_if(double x, int mask) {
+    return __hiloint2double(__double2hiint(x) & ~mask, __double2loint(x) & ~mask);
+}
+
+// One block of the pair form: 8 entries of this lane in `cur`, `o` = slot of the first pair that ends in the lane's
+// group.  Written for instruction count (the kernel is VALU-issue bound): pair ends are 0 / -1 masks taken from the
+// entries by bit-field extracts, nothing branches on them.
+//   pass 1  the lane's open tail (sum behind its last pair end) -> segmented wave scan -> the open sum that enters
+//           the lane (carry);
+//   pass 2  the running sum starts at the carry; at every entry it is written to the wave's LDS stage -- to the
+//           pair's ordinal if the entry ends a pair, to a dummy slot otherwise -- and cleared behind a pair end;
+//   then the staged sums leave as runs of consecutive slots (a lane's own stores would each be an L2 request).
 template <typename S>
-__device__ __forceinline__ void prc_pair_block(const S* __restrict__ s_tile, const prc_u32x4 cur, const int32_t o,
-                                               S* __restrict__ val, const int lane) {
+__device__ __forceinline__ void prc_pair_block(const S* __restrict__ s_tile, S* __restrict__ stage, const prc_u32x4 cur,
+                                               const int32_t o, S* __restrict__ val, const unsigned sink, const int lane) {
+    constexpr int CAP = PRC_STAGE_BYTES / (int) sizeof(S);   // staged pair sums per pass (fp32: a whole block's)
     const unsigned w[4] = {cur.x, cur.y, cur.z, cur.w};
-    double sum[8];
-    unsigned fl = 0;
-    double acc = 0.0;
+    S fv[8];
+    int m[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-        const unsigned e = (w[u >> 1] >> (16 * (u & 1))) & 0xffffu;
-        acc += (double) s_tile[e & 0x7fffu];
-        sum[u] = acc;
-        if (e & PRC_END) {
-            fl |= 1u << u;
-            acc = 0.0;
-        }
+        fv[u] = s_tile[__builtin_amdgcn_ubfe(w[u >> 1], 16 * (u & 1), 15)];
+        m[u] = __builtin_amdgcn_sbfe((int) w[u >> 1], 16 * (u & 1) + 15, 1);   // -1: last entry of its pair
     }
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc = prc_clear_if(acc + (double) fv[u], m[u]);
+    const int many = (m[0] | m[1]) | (m[2] | m[3]) | ((m[4] | m[5]) | (m[6] | m[7]));
+    const int cnt = -(((m[0] + m[1]) + (m[2] + m[3])) + ((m[4] + m[5]) + (m[6] + m[7])));
     // open sums across lanes: segmented inclusive scan (a lane holding a pair end restarts the segment); four steps
     // inside the rows of 16 lanes, then the row totals travel to the later rows
     double v = acc;
-    int f = fl != 0;
+    int f = many & 1;
     prc_seg_step<PRC_DPP_ROW_SHR(1), 0xf>(v, f);
     prc_seg_step<PRC_DPP_ROW_SHR(2), 0xf>(v, f);
     prc_seg_step<PRC_DPP_ROW_SHR(4), 0xf>(v, f);
@@ -347,37 +373,128 @@ __device__ __forceinline__ void prc_pair_block(const S* __restrict__ s_tile, con
     prc_seg_step<PRC_DPP_BCAST15, 0xa>(v, f);
     prc_seg_step<PRC_DPP_BCAST31, 0xc>(v, f);
     const double carry = prc_dpp_d<PRC_DPP_WAVE_SHR1, 0xf>(v);   // lane 0 reads 0: pairs never cross a block start
-    // slot of this lane's first pair end: the group's base + the ends of the group's earlier lanes
-    const int cnt = __builtin_popcount(fl);
+    // ordinal of this lane's first pair inside the block (exclusive wave scan of the counts) ...
+    int inc = cnt;
+    inc += prc_dpp_i<PRC_DPP_ROW_SHR(1), 0xf>(inc);
+    inc += prc_dpp_i<PRC_DPP_ROW_SHR(2), 0xf>(inc);
+    inc += prc_dpp_i<PRC_DPP_ROW_SHR(4), 0xf>(inc);
+    inc += prc_dpp_i<PRC_DPP_ROW_SHR(8), 0xf>(inc);
+    inc += prc_dpp_i<PRC_DPP_BCAST15, 0xa>(inc);
+    inc += prc_dpp_i<PRC_DPP_BCAST31, 0xc>(inc);
+    const int total = __builtin_amdgcn_readlane(inc, 63);
+    const int base = inc - cnt;
+    // ... and of the group's first pair: slot = ordinal + shift, with one shift per group (equal for the groups of a cell)
     const int c1 = prc_dpp_i<PRC_DPP_ROW_SHR(1), 0xf>(cnt), c2 = prc_dpp_i<PRC_DPP_ROW_SHR(2), 0xf>(cnt),
               c3 = prc_dpp_i<PRC_DPP_ROW_SHR(3), 0xf>(cnt);
     const int q = lane & 3;
-    S* dst = val + (int64_t) o + ((q >= 1 ? c1 : 0) + (q >= 2 ? c2 : 0) + (q >= 3 ? c3 : 0));
-    bool first = true;
+    const int gbase = base - ((q >= 1 ? c1 : 0) + (q >= 2 ? c2 : 0) + (q >= 3 ? c3 : 0));
+    const int shift = o - gbase;
+    int gcnt = cnt + __builtin_amdgcn_update_dpp(0, cnt, 0xb1, 0xf, 0xf, false);     // quad_perm [1,0,3,2]
+    gcnt += __builtin_amdgcn_update_dpp(0, gcnt, 0x4e, 0xf, 0xf, false);              // quad_perm [2,3,0,1]: pairs ending in the group
+    const unsigned long long live = __ballot(gcnt > 0);   // groups without a pair end (padding) have no say
+    const int shift0 = __builtin_amdgcn_readlane(shift, live ? __builtin_ctzll(live) : 0);
+    const bool one_run = __ballot(gcnt > 0 && shift != shift0) == 0ull;   // one cell, or cells that follow each other
+    // Every block issues exactly 8 store instructions (lanes with nothing to store write to their sink slot), on
+    // either path: the compiler can then count the stores between a prefetch and its use exactly, instead of
+    // draining every outstanding load and store (s_waitcnt vmcnt(0)) in front of each block.
+    constexpr int NPASS = PRC_BLK_GROUPS * PRC_G / CAP;   // fp32: 1, fp64: 2
+    constexpr int ROUNDS = CAP / 64;                       // store rounds per pass: NPASS * ROUNDS == 8
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-        if (fl & (1u << u)) {
-            double x = sum[u];
-            if (first) x += carry;
-            first = false;
-            *dst++ = (S) x;
+    for (int p = 0; p < NPASS; p++) {
+        const int p0 = p * CAP;
+        int ord = base - p0;
+        const int dummy = CAP + lane;
+        S xs[8];
+        int os[8];
+        acc = carry;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            acc += (double) fv[u];
+            xs[u] = (S) acc;
+            os[u] = ord;
+            int at = (ord & m[u]) | (dummy & ~m[u]);
+            if (NPASS > 1) at = (unsigned) at < (unsigned) CAP ? at : dummy;
+            stage[at] = xs[u];
+            ord -= m[u];
+            acc = prc_clear_if(acc, m[u]);
         }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+        int p1 = total - p0;                    // staged ordinals [0, p1) = block ordinals [p0, p0 + p1)
+        p1 = p1 < 0 ? 0 : (p1 > CAP ? CAP : p1);
+        if (one_run) {
+#pragma unroll
+            for (int r = 0; r < ROUNDS; r++) {
+                const int i = lane + 64 * r;
+                const unsigned at = i < p1 ? (unsigned) (shift0 + p0 + i) : sink;
+                val[at] = stage[i];
+            }
+        } else {
+            // the block spans cells that are not adjacent in the bin-major order: every lane stores its own pair ends
+#pragma unroll
+            for (int u = p * ROUNDS; u < (p + 1) * ROUNDS; u++) {
+                const unsigned at = m[u] ? (unsigned) (shift + p0 + os[u]) : sink;
+                val[at] = xs[u];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
-// Phase 1, pair form.  Work item = (tile, groups [g0, g1)), g0 and g1 on block boundaries.  A wave walks its blocks
-// PRC_PAIR_DEPTH at a time and keeps the entries of the next PRC_PAIR_DEPTH in flight (64 KiB per CU): the stream
-// comes from HBM, ~2 us away.
+// Phase 1, pair form.  Work item = (tile, groups [g0, g1)) with a whole number of super-steps: a wave walks its blocks
+// PRC_PAIR_DEPTH at a time (block (k * DEPTH + j) * 16 + wave) and keeps the entries of the next PRC_PAIR_DEPTH in
+// flight (64 KiB per CU) -- the stream comes from HBM, ~2 us away.
+//
+// The prefetch loads are inline asm with hand-counted waits.  hipcc's own bookkeeping turned every variant of this
+// loop into "s_waitcnt vmcnt(0)" (or a register rotation) in front of each block, i.e. into draining the loads it had
+// just issued together with every store of the previous blocks: the kernel then runs at the latency of one block
+// per round trip.  VMEM operations retire in issue order and every block issues exactly 8 stores (prc_pair_block),
+// so the count is exact: behind the loads of a set of blocks come the 8 * DEPTH stores of the set processed meanwhile
+// and the 2 * DEPTH loads of the next set -- waiting for vmcnt <= 10 * DEPTH leaves exactly those in flight.  The two
+// sets live in two named register groups (no rotation, so no copy of a register whose load is still in flight), and
+// the wait statement names every destination "+v", so nothing reads them before it.
 #define PRC_PAIR_DEPTH 4
+#define PRC_SUPER_GROUPS (PRC_WAVES * PRC_PAIR_DEPTH * PRC_BLK_GROUPS)   // groups per super-step of a workgroup (1024)
+#define PRC_STR2(x) #x
+#define PRC_STR(x) PRC_STR2(x)
+struct prc_set {   // the entries of PRC_PAIR_DEPTH blocks of one lane
+    prc_u32x4 e0, e1, e2, e3;
+    int32_t o0, o1, o2, o3;
+};
+__device__ __forceinline__ void prc_set_load(prc_set& t, const prc_u32x4* in, const int32_t* ob) {
+    static_assert(PRC_PAIR_DEPTH == 4, "prc_set holds four blocks");
+    asm volatile("global_load_dwordx4 %0, %8, off nt\n\t"
+                 "global_load_dwordx4 %1, %9, off nt\n\t"
+                 "global_load_dwordx4 %2, %10, off nt\n\t"
+                 "global_load_dwordx4 %3, %11, off nt\n\t"
+                 "global_load_dword %4, %12, off nt\n\t"
+                 "global_load_dword %5, %13, off nt\n\t"
+                 "global_load_dword %6, %14, off nt\n\t"
+                 "global_load_dword %7, %15, off nt"
+                 : "=&v"(t.e0), "=&v"(t.e1), "=&v"(t.e2), "=&v"(t.e3), "=&v"(t.o0), "=&v"(t.o1), "=&v"(t.o2), "=&v"(t.o3)
+                 : "v"(in), "v"(in + PRC_WAVES * 64), "v"(in + 2 * PRC_WAVES * 64), "v"(in + 3 * PRC_WAVES * 64),
+                   "v"(ob), "v"(ob + PRC_WAVES * PRC_BLK_GROUPS), "v"(ob + 2 * PRC_WAVES * PRC_BLK_GROUPS), "v"(ob + 3 * PRC_WAVES * PRC_BLK_GROUPS)
+                 : "memory");
+}
+// N = VMEM operations issued after the set's loads that may still be in flight
+#define PRC_SET_WAIT(t, N)                                                                                         \
+    asm volatile("s_waitcnt vmcnt(" PRC_STR(N) ")"                                                                  \
+                 : "+v"((t).e0), "+v"((t).e1), "+v"((t).e2), "+v"((t).e3), "+v"((t).o0), "+v"((t).o1), "+v"((t).o2), "+v"((t).o3) \
+                 :: "memory")
+
 template <typename S, int TILE>
 __global__ void __launch_bounds__(PRC_THREADS)
 pr_cold_pair_kernel(const prc_item1* __restrict__ items, int n_items, unsigned int* __restrict__ queue,
-                    const S* __restrict__ contrib, int64_t ncold, int64_t span, int64_t slice, int64_t T,
-                    const uint16_t* __restrict__ srcl, const int32_t* __restrict__ ob, S* __restrict__ val) {
+                    const S* __restrict__ contrib, const int32_t* __restrict__ org, int nranks, int64_t span, int64_t slice, int64_t T,
+                    const uint16_t* __restrict__ srcl, const int32_t* __restrict__ ob, S* __restrict__ val, unsigned sink_base) {
     __shared__ S s_tile[TILE];
+    __shared__ S s_stage[PRC_WAVES][PRC_STAGE_BYTES / sizeof(S) + 64];   // + a dummy slot per lane
     __shared__ int s_item;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    S* stage = s_stage[wv];
+    const unsigned sink = sink_base + (blockIdx.x * PRC_WAVES + wv) * 64 + lane;   // where a lane's idle stores go
     int loaded = -1;
     for (;;) {
         __syncthreads();   // everybody is done with s_item and the tile of the previous item
@@ -386,46 +503,51 @@ pr_cold_pair_kernel(const prc_item1* __restrict__ items, int n_items, unsigned i
         const int it = s_item;
         if (it >= n_items) break;
         const prc_item1 d = items[it];
-        const int nb = (d.g1 - d.g0) / PRC_BLK_GROUPS;
-        const prc_u32x4* in = (const prc_u32x4*) srcl + (int64_t) d.g0 * (PRC_G / 8) + lane;   // 8 entries per lane
-        const int32_t* obp = ob + d.g0 + (lane >> 2);
-        prc_u32x4 cur[PRC_PAIR_DEPTH], nxt[PRC_PAIR_DEPTH];
-        int32_t ocur[PRC_PAIR_DEPTH], onxt[PRC_PAIR_DEPTH];
-#pragma unroll
-        for (int j = 0; j < PRC_PAIR_DEPTH; j++) {   // the first blocks travel while the tile is loaded
-            const int b = wv + j * PRC_WAVES;
-            cur[j] = prc_u32x4{0, 0, 0, 0};
-            ocur[j] = 0;
-            if (b < nb) {
-                cur[j] = __builtin_nontemporal_load(in + (int64_t) b * 64);
-                ocur[j] = __builtin_nontemporal_load(obp + b * PRC_BLK_GROUPS);
-            }
-        }
+        const int nsuper = (d.g1 - d.g0) / PRC_SUPER_GROUPS;
+        // 8 entries per lane; block b of the item starts 64 vectors (16 groups) after block b - 1
+        const prc_u32x4* in = (const prc_u32x4*) srcl + ((int64_t) d.g0 * (PRC_G / 8) + wv * 64 + lane);
+        const int32_t* obp = ob + (d.g0 + wv * PRC_BLK_GROUPS + (lane >> 2));
+        constexpr int64_t IN_STEP = PRC_PAIR_DEPTH * PRC_WAVES * 64;
+        constexpr int64_t OB_STEP = PRC_PAIR_DEPTH * PRC_WAVES * PRC_BLK_GROUPS;
         if (d.tile != loaded) {   // (workgroup-uniform) chunks of one tile often follow each other
-            prc_load_tile<S, TILE>(s_tile, d.tile, contrib, ncold, span, slice, T);
+            prc_load_tile<S, TILE>(s_tile, d.tile, org, contrib, nranks, span, slice, T);
             loaded = d.tile;
             __syncthreads();
         }
-        for (int b0 = wv; b0 < nb; b0 += PRC_WAVES * PRC_PAIR_DEPTH) {
-#pragma unroll
-            for (int j = 0; j < PRC_PAIR_DEPTH; j++) {
-                const int b = b0 + (PRC_PAIR_DEPTH + j) * PRC_WAVES;
-                nxt[j] = prc_u32x4{0, 0, 0, 0};
-                onxt[j] = 0;
-                if (b < nb) {
-                    nxt[j] = __builtin_nontemporal_load(in + (int64_t) b * 64);
-                    onxt[j] = __builtin_nontemporal_load(obp + b * PRC_BLK_GROUPS);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < PRC_PAIR_DEPTH; j++)
-                if (b0 + j * PRC_WAVES < nb) prc_pair_block<S>(s_tile, cur[j], ocur[j], val, lane);
-#pragma unroll
-            for (int j = 0; j < PRC_PAIR_DEPTH; j++) {
-                cur[j] = nxt[j];
-                ocur[j] = onxt[j];
-            }
+        prc_set A, B;
+#define PRC_PROCESS(t)                                                    \
+    do {                                                                  \
+        prc_pair_block<S>(s_tile, stage, (t).e0, (t).o0, val, sink, lane); \
+        prc_pair_block<S>(s_tile, stage, (t).e1, (t).o1, val, sink, lane); \
+        prc_pair_block<S>(s_tile, stage, (t).e2, (t).o2, val, sink, lane); \
+        prc_pair_block<S>(s_tile, stage, (t).e3, (t).o3, val, sink, lane); \
+    } while (0)
+        // super-step 0 (set A): only the loads of super-step 1 are younger
+        prc_set_load(A, in, obp);
+        {
+            const int kn = 1 < nsuper ? 1 : 0;
+            prc_set_load(B, in + kn * IN_STEP, obp + kn * OB_STEP);
         }
+        PRC_SET_WAIT(A, 8);
+        PRC_PROCESS(A);
+        int k = 1;
+#pragma unroll 1
+        for (; k + 1 < nsuper; k += 2) {
+            prc_set_load(A, in + (int64_t) (k + 1) * IN_STEP, obp + (int64_t) (k + 1) * OB_STEP);
+            PRC_SET_WAIT(B, 40);   // 32 stores of the previous super-step + the 8 loads just issued
+            PRC_PROCESS(B);
+            const int kn = k + 2 < nsuper ? k + 2 : k + 1;
+            prc_set_load(B, in + (int64_t) kn * IN_STEP, obp + (int64_t) kn * OB_STEP);
+            PRC_SET_WAIT(A, 40);
+            PRC_PROCESS(A);
+        }
+        if (k < nsuper) {   // one super-step left, in B; nothing younger than the stores of the previous one
+            PRC_SET_WAIT(B, 32);
+            PRC_PROCESS(B);
+        } else {
+            PRC_SET_WAIT(B, 0);   // the redundant prefetch of the last super-step: land before B is loaded again
+        }
+#undef PRC_PROCESS
     }
 }
 
@@ -434,7 +556,7 @@ pr_cold_pair_kernel(const prc_item1* __restrict__ items, int n_items, unsigned i
 template <typename S, int TILE>
 __global__ void __launch_bounds__(PRC_THREADS)
 pr_cold_gather_kernel(const prc_item1* __restrict__ items, int n_items, unsigned int* __restrict__ queue,
-                      const S* __restrict__ contrib, int64_t ncold, int64_t span, int64_t slice, int64_t T,
+                      const S* __restrict__ contrib, const int32_t* __restrict__ org, int nranks, int64_t span, int64_t slice, int64_t T,
                       const uint16_t* __restrict__ srcl, const int32_t* __restrict__ ob, S* __restrict__ val) {
     typedef typename prc_vec4<S>::type V4;
     __shared__ S s_tile[TILE];
@@ -450,7 +572,7 @@ pr_cold_gather_kernel(const prc_item1* __restrict__ items, int n_items, unsigned
         if (it >= n_items) break;
         const prc_item1 d = items[it];
         if (d.tile != loaded) {
-            prc_load_tile<S, TILE>(s_tile, d.tile, contrib, ncold, span, slice, T);
+            prc_load_tile<S, TILE>(s_tile, d.tile, org, contrib, nranks, span, slice, T);
             loaded = d.tile;
             __syncthreads();
         }
@@ -487,13 +609,43 @@ pr_cold_gather_kernel(const prc_item1* __restrict__ items, int n_items, unsigned
 // holds what the first one truncates, with lo_bits chosen at plan time from the largest number of terms.
 __device__ __forceinline__ unsigned long long prc_fix_hi(double v) { return (unsigned long long) (long long) (v * 0x1p62); }
 
-template <typename S, int BINROWS, int LIMBS>
+// The PageRank update of active row i from its finished neighbour sum (pagerank.gm:13-16; what pr_combine_kernel
+// does when the pull sweep has a share): val = (1-d)/N + d * sum, diff += |val - rank|, new rank and contribution.
+template <typename S>
+__device__ __forceinline__ void prc_finish_row(const pr_cold_fuse& fz, int64_t i, double sum, double& diff_acc) {
+    const int32_t od = __builtin_nontemporal_load(fz.outdeg_c + i);
+    const int64_t r = __builtin_nontemporal_load(fz.active + i);
+    const double old = (double) __builtin_nontemporal_load((const S*) fz.rk_c + i);
+    const S vs = (S) (fz.base + fz.d * sum);
+    diff_acc += fabs((double) vs - old);
+    __builtin_nontemporal_store(vs, (S*) fz.rk_c + i);
+    __builtin_nontemporal_store(od > 0 ? (S) ((double) vs / (double) od) : (S) 0, (S*) fz.next_owned + r);
+}
+
+// sum of the block's diff_acc in a fixed order (lanes by shuffles, then the waves in order) -> *dst
+template <int THREADS>
+__device__ __forceinline__ void prc_block_diff(double diff_acc, double* s_red, double* __restrict__ dst) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) diff_acc += __shfl_down(diff_acc, off, 64);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = diff_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; w++) t += s_red[w];
+        *dst = t;
+    }
+}
+
+template <typename S, int BINROWS, int LIMBS, bool FUSE>
 __global__ void __launch_bounds__(PRC_THREADS)
 pr_cold_accum_kernel(const prc_item2* __restrict__ items, int n_items, unsigned int* __restrict__ queue,
                      const uint16_t* __restrict__ rowl, const S* __restrict__ val, int64_t nactive, double lo_scale,
-                     S* __restrict__ cold, unsigned long long* __restrict__ scratch) {
+                     S* __restrict__ cold, unsigned long long* __restrict__ scratch, pr_cold_fuse fz,
+                     double* __restrict__ diff_part) {
     typedef typename prc_vec4<S>::type V4;
     __shared__ unsigned long long s_acc[LIMBS * BINROWS];
+    __shared__ double s_red[PRC_WAVES];
     __shared__ int s_item;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -541,30 +693,34 @@ pr_cold_accum_kernel(const prc_item2* __restrict__ items, int n_items, unsigned 
             }
         }
         __syncthreads();
+        double diff_acc = 0.0;
         if (d.slot < 0) {
             const int64_t i0 = (int64_t) d.bin * BINROWS;
 #pragma unroll 4
             for (int r = tid; r < BINROWS; r += PRC_THREADS) {
                 if (i0 + r >= nactive) break;
-                double s = (double) (long long) s_acc[r] * 0x1p-62;
-                if (LIMBS > 1) s += (double) (long long) s_acc[BINROWS + r] * (0x1p-62 / lo_scale);
-                __builtin_nontemporal_store((S) s, cold + i0 + r);
+                double sum = (double) (long long) s_acc[r] * 0x1p-62;
+                if (LIMBS > 1) sum += (double) (long long) s_acc[BINROWS + r] * (0x1p-62 / lo_scale);
+                if (FUSE) prc_finish_row<S>(fz, i0 + r, sum, diff_acc);
+                else __builtin_nontemporal_store((S) sum, cold + i0 + r);
             }
         } else {
             unsigned long long* dst = scratch + (int64_t) d.slot * (LIMBS * BINROWS);
 #pragma unroll 4
             for (int i = tid; i < LIMBS * BINROWS; i += PRC_THREADS) dst[i] = s_acc[i];
         }
+        if (FUSE) prc_block_diff<PRC_THREADS>(diff_acc, s_red, diff_part + it);   // one partial per work item (0 for chunks)
     }
 }
 
 // Phase 3.  A split bin's chunk accumulators (nslots x BINROWS, 128 KiB apart) are added per row: a block takes 64
 // consecutive rows (one 512-byte line set per slot and wave) and deals the slots to its 16 waves, which then meet
 // in LDS.  Integer adds: any order gives the same bits.
-template <typename S, int BINROWS, int LIMBS>
+template <typename S, int BINROWS, int LIMBS, bool FUSE>
 __global__ void __launch_bounds__(1024)
 pr_cold_reduce_kernel(const prc_item3* __restrict__ items, int64_t nactive, double lo_scale,
-                      const unsigned long long* __restrict__ scratch, S* __restrict__ cold) {
+                      const unsigned long long* __restrict__ scratch, S* __restrict__ cold, pr_cold_fuse fz,
+                      double* __restrict__ diff_part) {
     __shared__ unsigned long long s_part[LIMBS][16][64];
     const prc_item3 d = items[blockIdx.y];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -590,7 +746,21 @@ pr_cold_reduce_kernel(const prc_item3* __restrict__ items, int64_t nactive, doub
         }
         double v = (double) (long long) hi * 0x1p-62;
         if (LIMBS > 1) v += (double) (long long) lo * (0x1p-62 / lo_scale);
-        cold[i0 + r] = (S) v;
+        if (FUSE) {
+            double diff_acc = 0.0;
+            prc_finish_row<S>(fz, i0 + r, v, diff_acc);
+            s_part[0][0][lane] = (unsigned long long) __double_as_longlong(diff_acc);   // (wave 0 only: its own slots)
+        } else cold[i0 + r] = (S) v;
+    } else if (FUSE && wv == 0) s_part[0][0][lane] = 0ull;
+    if (FUSE && wv == 0) {   // the 64 rows' |val - rank| in lane order: one partial per block
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            double t = 0.0;
+            for (int l = 0; l < 64; l++) t += __longlong_as_double((long long) s_part[0][0][l]);
+            diff_part[(int64_t) blockIdx.y * gridDim.x + blockIdx.x] = t;
+        }
     }
 }
 
@@ -634,7 +804,7 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
     pr_cold* c = new pr_cold();
     c->prm = prm;
     c->Ec = Ec;
-    c->tile = PRC_LDS_BYTES / prm.elem;
+    c->tile = prc_tile_elems(prm.elem);
     const int tile_src = c->tile - 1;
     c->limbs = prm.elem == 4 ? 1 : 2;
     c->binrows = PRC_LDS_BYTES / 8 / c->limbs;
@@ -736,7 +906,7 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
         hmode[t] = (np > 0 && (double) ne >= pair_min * (double) np) ? 1 : 0;
         if (hmode[t]) { pair_edges += ne; pair_tiles++; }
         hdelta[t] = tstart[t] - ht[4 * t + 1];
-        tstart[t + 1] = tstart[t] + (int32_t) ((g + PRC_BLK_GROUPS - 1) / PRC_BLK_GROUPS * PRC_BLK_GROUPS);
+        tstart[t + 1] = tstart[t] + (int32_t) ((g + PRC_SUPER_GROUPS - 1) / PRC_SUPER_GROUPS * PRC_SUPER_GROUPS);   // pair form: whole super-steps
     }
     ngroups1 = tstart[c->ntiles];
     if (ngroups1 * PRC_G >= (1LL << 31)) {
@@ -796,10 +966,10 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
     PRC_ALLOC(c->srcl, c->P1);
     PRC_ALLOC(c->ob, ngroups1);
     PRC_ALLOC(c->rowl, c->P2);
-    PRC_ALLOC(c->val, (size_t) c->P2 * prm.elem);
+    PRC_ALLOC(c->val, ((size_t) c->P2 + (size_t) c->grid * PRC_THREADS) * prm.elem);   // + the sink slots of the pair kernel
     hipLaunchKernelGGL(prc_fill_u16_kernel, dim3(prc_grid_for(c->P1)), dim3(256), 0, s, c->srcl.p, c->P1, (uint16_t) tile_src);
     PRC_TRY(hipMemsetAsync(c->rowl.p, 0xff, (size_t) c->P2 * 2, s), "memset");
-    PRC_TRY(hipMemsetAsync(c->val.p, 0, (size_t) c->P2 * prm.elem, s), "memset");
+    PRC_TRY(hipMemsetAsync(c->val.p, 0, ((size_t) c->P2 + (size_t) c->grid * PRC_THREADS) * prm.elem, s), "memset");
     hipLaunchKernelGGL(prc_fill_items_kernel, dim3(prc_grid_for(Ec)), dim3(256), 0, s, sk, (const int32_t*) incl.p,
                        (const int32_t*) first.p, (const int32_t*) c1.p, (const int32_t*) c2.p, (const int32_t*) nat.p,
                        (const int32_t*) natpre.p, Ec, c->srcl.p, c->rowl.p);
@@ -819,10 +989,21 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
         if (c->lo_bits > 62) c->lo_bits = 62;
         if (c->lo_bits < 20) c->lo_bits = 20;
     }
+    {   // where the tiles start in the contribution replica
+        const int64_t span = prm.slice - prm.T;
+        std::vector<int32_t> horg((size_t) 2 * c->ntiles + 2, 0);
+        for (int64_t t = 0; t < c->ntiles; t++) {
+            const int64_t cp = t * (int64_t) tile_src;
+            horg[2 * t] = (int32_t) (cp / span);
+            horg[2 * t + 1] = (int32_t) (cp % span);
+        }
+        PRC_ALLOC(c->torg, horg.size());
+        PRC_TRY(hipMemcpy(c->torg.p, horg.data(), sizeof(int32_t) * horg.size(), hipMemcpyHostToDevice), "copy");
+    }
     // ---- work lists ----
     {
-        const int ch1 = std::max(PRC_BLK_GROUPS, prc_env_int("GMX_PR_COLD_CHUNK1", 8192)) / PRC_BLK_GROUPS * PRC_BLK_GROUPS;   // groups per phase-1 item
-        const int ch2 = std::max(8, prc_env_int("GMX_PR_COLD_CHUNK", 4096)) / 8 * 8;    // groups per phase-2 item (128 K items)
+        const int ch1 = std::max(PRC_SUPER_GROUPS, prc_env_int("GMX_PR_COLD_CHUNK1", 8192)) / PRC_SUPER_GROUPS * PRC_SUPER_GROUPS;   // groups per phase-1 item
+        const int ch2 = std::max(8, prc_env_int("GMX_PR_COLD_CHUNK", 32768)) / 8 * 8;   // groups per phase-2 item (1 Mi items): only hub bins are split
         for (int64_t t = 0; t < c->ntiles; t++) {
             const int32_t g0 = tstart[t];
             // pair tiles run whole blocks (the padding behind the last cell ends no pair); edge tiles stop at the
@@ -831,9 +1012,10 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
             for (int32_t g = g0; g < g1; g += ch1) (hmode[t] ? v1p : v1e).push_back({(int32_t) t, g, std::min(g1, g + ch1), 0});
         }
         int32_t slot = 0;
+        c->all_bins = true;
         for (int64_t b = 0; b < c->nbins; b++) {
             const int32_t g0 = h2[b], g1 = h2[b + 1];
-            if (g1 <= g0) continue;
+            if (g1 <= g0) { c->all_bins = false; continue; }
             if (g1 - g0 <= ch2) { v2.push_back({(int32_t) b, g0, g1, -1}); continue; }
             const int32_t s0 = slot;
             for (int32_t g = g0; g < g1; g += ch2) v2.push_back({(int32_t) b, g, std::min(g1, g + ch2), slot++});
@@ -854,12 +1036,27 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
         PRC_ALLOC(c->it2, std::max<size_t>(1, v2.size()));
         PRC_ALLOC(c->it3, std::max<size_t>(1, v3.size()));
         PRC_ALLOC(c->scratch, std::max<size_t>(1, (size_t) slot * c->limbs * c->binrows));
+        PRC_ALLOC(c->diffp, std::max<size_t>(1, v2.size() + v3.size() * (size_t) (c->binrows / 64)));
+        PRC_TRY(hipMemset(c->diffp.p, 0, sizeof(double) * std::max<size_t>(1, v2.size() + v3.size() * (size_t) (c->binrows / 64))), "memset");
         if (!v1p.empty()) PRC_TRY(hipMemcpy(c->it1p.p, v1p.data(), sizeof(prc_item1) * v1p.size(), hipMemcpyHostToDevice), "copy");
         if (!v1e.empty()) PRC_TRY(hipMemcpy(c->it1e.p, v1e.data(), sizeof(prc_item1) * v1e.size(), hipMemcpyHostToDevice), "copy");
         if (!v2.empty()) PRC_TRY(hipMemcpy(c->it2.p, v2.data(), sizeof(prc_item2) * v2.size(), hipMemcpyHostToDevice), "copy");
         if (!v3.empty()) PRC_TRY(hipMemcpy(c->it3.p, v3.data(), sizeof(prc_item3) * v3.size(), hipMemcpyHostToDevice), "copy");
     }
     PRC_TRY(hipStreamSynchronize(s), "sync");
+    if (getenv("GMX_PR_DEBUG")) {
+        std::vector<int64_t> bs;
+        for (int64_t b = 0; b < c->nbins; b++) bs.push_back(((int64_t) h2[b + 1] - h2[b]) * PRC_G);
+        std::sort(bs.begin(), bs.end());
+        int64_t over[4] = {0, 0, 0, 0}, lim[4] = {131072, 262144, 524288, 1048576}, sum_over[4] = {0, 0, 0, 0};
+        for (int64_t v : bs)
+            for (int q = 0; q < 4; q++)
+                if (v > lim[q]) { over[q]++; sum_over[q] += v; }
+        fprintf(stderr, "gmx pr cold: bin items min %lld median %lld p90 %lld max %lld; bins over 128K/256K/512K/1M items: %lld/%lld/%lld/%lld holding %lld/%lld/%lld/%lld items\n",
+                (long long) bs.front(), (long long) bs[bs.size() / 2], (long long) bs[bs.size() * 9 / 10], (long long) bs.back(),
+                (long long) over[0], (long long) over[1], (long long) over[2], (long long) over[3], (long long) sum_over[0],
+                (long long) sum_over[1], (long long) sum_over[2], (long long) sum_over[3]);
+    }
     if (getenv("GMX_PR_DEBUG"))
         fprintf(stderr, "gmx pr cold: T %lld, %lld edges -> %lld entries in %lld cells (%lld tiles x %lld bins); %lld pair tiles with %lld edges; "
                 "%lld pairs -> %lld items; work items %lld + %lld / %lld / %lld, %lld slots, lo_bits %d\n", (long long) prm.T, (long long) Ec,
@@ -881,9 +1078,9 @@ const void* pr_cold_partial(const pr_cold* c) { return c ? (const void*) c->cold
 int64_t pr_cold_edges(const pr_cold* c) { return c ? c->Ec : 0; }
 int64_t pr_cold_items(const pr_cold* c) { return c ? c->P2 : 0; }
 
-template <typename S>
-static void prc_launch(pr_cold* c, const void* contrib, hipStream_t s) {
-    constexpr int TILE = PRC_LDS_BYTES / (int) sizeof(S);
+template <typename S, bool FUSE>
+static void prc_launch(pr_cold* c, const void* contrib, const pr_cold_fuse& fz, hipStream_t s) {
+    constexpr int TILE = prc_tile_elems((int) sizeof(S));
     constexpr int LIMBS = sizeof(S) == 4 ? 1 : 2;
     constexpr int BINROWS = PRC_LDS_BYTES / 8 / LIMBS;
     const double lo_scale = ldexp(1.0, c->lo_bits);
@@ -891,23 +1088,41 @@ static void prc_launch(pr_cold* c, const void* contrib, hipStream_t s) {
     (void) hipMemsetAsync(c->queue.p, 0, 3 * 64 * sizeof(unsigned int), s);
     if (c->n1p > 0)
         hipLaunchKernelGGL((pr_cold_pair_kernel<S, TILE>), dim3((unsigned) std::min<int64_t>(c->grid, c->n1p)), dim3(PRC_THREADS), 0, s,
-                           (const prc_item1*) c->it1p.p, (int) c->n1p, c->queue.p, (const S*) contrib, c->ncold, span, c->prm.slice,
-                           c->prm.T, (const uint16_t*) c->srcl.p, (const int32_t*) c->ob.p, (S*) c->val.p);
+                           (const prc_item1*) c->it1p.p, (int) c->n1p, c->queue.p, (const S*) contrib, (const int32_t*) c->torg.p, c->prm.nranks, span, c->prm.slice,
+                           c->prm.T, (const uint16_t*) c->srcl.p, (const int32_t*) c->ob.p, (S*) c->val.p, (unsigned) c->P2);
     if (c->n1e > 0)
         hipLaunchKernelGGL((pr_cold_gather_kernel<S, TILE>), dim3((unsigned) std::min<int64_t>(c->grid, c->n1e)), dim3(PRC_THREADS), 0, s,
-                           (const prc_item1*) c->it1e.p, (int) c->n1e, c->queue.p, (const S*) contrib, c->ncold, span, c->prm.slice,
+                           (const prc_item1*) c->it1e.p, (int) c->n1e, c->queue.p, (const S*) contrib, (const int32_t*) c->torg.p, c->prm.nranks, span, c->prm.slice,
                            c->prm.T, (const uint16_t*) c->srcl.p, (const int32_t*) c->ob.p, (S*) c->val.p);
-    hipLaunchKernelGGL((pr_cold_accum_kernel<S, BINROWS, LIMBS>), dim3((unsigned) std::min<int64_t>(c->grid, c->n2)), dim3(PRC_THREADS), 0, s,
+    hipLaunchKernelGGL((pr_cold_accum_kernel<S, BINROWS, LIMBS, FUSE>), dim3((unsigned) std::min<int64_t>(c->grid, c->n2)), dim3(PRC_THREADS), 0, s,
                        (const prc_item2*) c->it2.p, (int) c->n2, c->queue.p, (const uint16_t*) c->rowl.p, (const S*) c->val.p,
-                       c->prm.nactive, lo_scale, (S*) c->cold.p, c->scratch.p);
+                       c->prm.nactive, lo_scale, (S*) c->cold.p, c->scratch.p, fz, c->diffp.p);
     if (c->n3 > 0)
-        hipLaunchKernelGGL((pr_cold_reduce_kernel<S, BINROWS, LIMBS>), dim3(BINROWS / 64, (unsigned) c->n3), dim3(1024), 0, s,
-                           (const prc_item3*) c->it3.p, c->prm.nactive, lo_scale, (const unsigned long long*) c->scratch.p, (S*) c->cold.p);
+        hipLaunchKernelGGL((pr_cold_reduce_kernel<S, BINROWS, LIMBS, FUSE>), dim3(BINROWS / 64, (unsigned) c->n3), dim3(1024), 0, s,
+                           (const prc_item3*) c->it3.p, c->prm.nactive, lo_scale, (const unsigned long long*) c->scratch.p, (S*) c->cold.p,
+                           fz, c->diffp.p + c->n2);
 }
 
-int pr_cold_launch(pr_cold* c, const void* contrib, hipStream_t s) {
+// fuse == NULL: leave the row sums in pr_cold_partial().  Otherwise apply the PageRank update right where a row's sum
+// is finished (needs every edge binned and every bin with rows to own an item) and leave |val - rank| partials in
+// pr_cold_diff_partials().
+int pr_cold_launch(pr_cold* c, const void* contrib, const pr_cold_fuse* fuse, hipStream_t s) {
     if (!c || c->Ec == 0 || c->n2 == 0) return GMX_OK;
-    if (c->prm.elem == 4) prc_launch<float>(c, contrib, s);
-    else prc_launch<double>(c, contrib, s);
+    const pr_cold_fuse none{};
+    if (c->prm.elem == 4) {
+        if (fuse) prc_launch<float, true>(c, contrib, *fuse, s);
+        else prc_launch<float, false>(c, contrib, none, s);
+    } else {
+        if (fuse) prc_launch<double, true>(c, contrib, *fuse, s);
+        else prc_launch<double, false>(c, contrib, none, s);
+    }
     return GMX_OK;
 }
+
+const double* pr_cold_diff_partials(const pr_cold* c, int64_t* n) {
+    *n = c ? c->n2 + c->n3 * (c->binrows / 64) : 0;
+    return c ? c->diffp.p : nullptr;
+}
+
+// every active row lies in a bin that has at least one item: the fused finish then visits all of them
+bool pr_cold_covers_all_rows(const pr_cold* c) { return c && c->all_bins; }
