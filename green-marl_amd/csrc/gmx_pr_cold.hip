@@ -14,12 +14,12 @@
 //                are contiguous in both orders, a bin's cells follow each other.
 //
 //   phase 1  one workgroup per tile (big tiles are cut into chunks): contribution tile -> LDS (coalesced), then
-//            * pr_cold_pair_kernel  (tiles whose pairs average >= 1.25 edges -- the hot sources): every wave takes
+//            * pair form  (pr_cold_tile_kernel; tiles whose pairs average >= 1.25 edges -- the hot sources): every wave takes
 //              blocks of 512 edges, a lane 8 consecutive ones (one 16-byte load), gathers from LDS, sums in fp64
 //              along the lane, closes pairs that span lanes with a segmented wave scan (__shfl_up) and stores one
 //              value per pair.  Pairs are cut at block ends at plan time (a longer pair simply becomes several
 //              items of the same row), so a block needs nothing from its neighbours: no fix-up pass.
-//            * pr_cold_gather_kernel (tiles where almost every pair is a single edge -- the cold tail): every edge is
+//            * edge form  (same kernel, same queue; tiles where almost every pair is a single edge -- the cold tail): every edge is
 //              an item; 8 lanes copy a group with one 8-byte load, four LDS reads and one 16-byte store each, so
 //              every store instruction writes whole aligned 128-byte lines.
 //            The only metadata is one int per group of 32 edges (slot of the first pair that ends in the group).
@@ -56,7 +56,7 @@ static constexpr int prc_tile_elems(int elem) { return (PRC_LDS_LIMIT - 16 * (PR
 #define PRC_Q1E 64
 #define PRC_Q2 128
 
-struct prc_item1 { int32_t tile, g0, g1, pad; };          // phase 1: groups [g0, g1) of the tile-major stream
+struct prc_item1 { int32_t tile, g0, g1, form; };         // phase 1: groups [g0, g1) of the tile-major stream; form 1 = pair, 0 = edge
 struct prc_item2 { int32_t bin, g0, g1, slot; };          // phase 2: groups [g0, g1) of the bin-major stream; slot < 0: sole chunk
 struct prc_item3 { int32_t bin, slot0, nslots, pad; };    // phase 3: a split bin
 
@@ -74,7 +74,7 @@ struct pr_cold {
     dbuf<uint16_t> rowl;     // [P2] bin-major row numbers
     dbuf<char> val;          // [P2] x elem, bin-major: written by phase 1, read by phase 2
     dbuf<char> cold;         // [nactive] x elem
-    dbuf<prc_item1> it1p, it1e;
+    dbuf<prc_item1> it1p;    // pair items, then edge items
     dbuf<int32_t> torg;      // [2 * ntiles] rank range and offset behind the hot/cold border where a tile starts
     dbuf<prc_item2> it2;
     dbuf<prc_item3> it3;
@@ -316,7 +316,7 @@ __device__ __forceinline__ void prc_load_tile(S* __restrict__ s_tile, int tile, 
 #define PRC_DPP_BCAST31 0x143
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int prc_dpp_i(int v) {   // lanes without a source (or outside ROW_MASK) read 0
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);   // all rows written: no need to preset the result
 }
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double prc_dpp_d(double v) {
@@ -483,9 +483,92 @@ __device__ __forceinline__ void prc_set_load(prc_set& t, const prc_u32x4* in, co
                  : "+v"((t).e0), "+v"((t).e1), "+v"((t).e2), "+v"((t).e3), "+v"((t).o0), "+v"((t).o1), "+v"((t).o2), "+v"((t).o3) \
                  :: "memory")
 
+// the pair form of one work item (see above); the tile is in LDS
+template <typename S>
+__device__ __forceinline__ void prc_pair_item(const prc_item1 d, const S* __restrict__ s_tile, S* __restrict__ stage,
+                                              const uint16_t* __restrict__ srcl, const int32_t* __restrict__ ob,
+                                              S* __restrict__ val, const unsigned sink, const int wv, const int lane) {
+    const int nsuper = (d.g1 - d.g0) / PRC_SUPER_GROUPS;
+    // 8 entries per lane; block b of the item starts 64 vectors (16 groups) after block b - 1
+    const prc_u32x4* in = (const prc_u32x4*) srcl + ((int64_t) d.g0 * (PRC_G / 8) + wv * 64 + lane);
+    const int32_t* obp = ob + (d.g0 + wv * PRC_BLK_GROUPS + (lane >> 2));
+    constexpr int64_t IN_STEP = PRC_PAIR_DEPTH * PRC_WAVES * 64;
+    constexpr int64_t OB_STEP = PRC_PAIR_DEPTH * PRC_WAVES * PRC_BLK_GROUPS;
+    prc_set A, B;
+#define PRC_PROCESS(t)                                                    \
+    do {                                                                  \
+        prc_pair_block<S>(s_tile, stage, (t).e0, (t).o0, val, sink, lane); \
+        prc_pair_block<S>(s_tile, stage, (t).e1, (t).o1, val, sink, lane); \
+        prc_pair_block<S>(s_tile, stage, (t).e2, (t).o2, val, sink, lane); \
+        prc_pair_block<S>(s_tile, stage, (t).e3, (t).o3, val, sink, lane); \
+    } while (0)
+    // super-step 0 (set A): only the loads of super-step 1 are younger
+    prc_set_load(A, in, obp);
+    {
+        const int kn = 1 < nsuper ? 1 : 0;
+        prc_set_load(B, in + kn * IN_STEP, obp + kn * OB_STEP);
+    }
+    PRC_SET_WAIT(A, 8);
+    PRC_PROCESS(A);
+    int k = 1;
+#pragma unroll 1
+    for (; k + 1 < nsuper; k += 2) {
+        prc_set_load(A, in + (int64_t) (k + 1) * IN_STEP, obp + (int64_t) (k + 1) * OB_STEP);
+        PRC_SET_WAIT(B, 40);   // 32 stores of the previous super-step + the 8 loads just issued
+        PRC_PROCESS(B);
+        const int kn = k + 2 < nsuper ? k + 2 : k + 1;
+        prc_set_load(B, in + (int64_t) kn * IN_STEP, obp + (int64_t) kn * OB_STEP);
+        PRC_SET_WAIT(A, 40);
+        PRC_PROCESS(A);
+    }
+    if (k < nsuper) {   // one super-step left, in B; nothing younger than the stores of the previous one
+        PRC_SET_WAIT(B, 32);
+        PRC_PROCESS(B);
+    } else {
+        PRC_SET_WAIT(B, 0);   // the redundant prefetch of the last super-step: land before B is loaded again
+    }
+#undef PRC_PROCESS
+}
+
+// The edge form of one work item: every entry is an item.  A lane handles 4 consecutive entries of one group: one
+// 8-byte load, four LDS reads, one 16/32-byte store; 8 lanes cover a group, a wave 8 groups ("piece") per instruction.
+template <typename S>
+__device__ __forceinline__ void prc_edge_item(const prc_item1 d, const S* __restrict__ s_tile,
+                                              const uint16_t* __restrict__ srcl, const int32_t* __restrict__ ob,
+                                              S* __restrict__ val, const int wv, const int lane) {
+    typedef typename prc_vec4<S>::type V4;
+    const int npieces = (d.g1 - d.g0 + 7) >> 3;
+    for (int base = 0; base < npieces; base += PRC_WAVES * PRC_UNROLL) {
+        prc_u32x2 ids[PRC_UNROLL];
+        int32_t o[PRC_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PRC_UNROLL; u++) {
+            const int pc = base + u * PRC_WAVES + wv;
+            const int g = d.g0 + pc * 8 + (lane >> 3);
+            o[u] = -1;
+            if (pc < npieces && g < d.g1) {
+                ids[u] = __builtin_nontemporal_load((const prc_u32x2*) srcl + (int64_t) g * (PRC_G / 4) + (lane & 7));
+                o[u] = __builtin_nontemporal_load(ob + g);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PRC_UNROLL; u++) {
+            if (o[u] < 0) continue;
+            V4 v;
+            v.x = s_tile[ids[u].x & 0x7fffu];
+            v.y = s_tile[(ids[u].x >> 16) & 0x7fffu];
+            v.z = s_tile[ids[u].y & 0x7fffu];
+            v.w = s_tile[(ids[u].y >> 16) & 0x7fffu];
+            __builtin_nontemporal_store(v, (V4*) (val + o[u]) + (lane & 7));   // o is a multiple of G: aligned lines
+        }
+    }
+}
+
+// Phase 1: one queue for both forms (item.form: 1 = pair, 0 = edge); the big pair items come first, the small
+// edge items of the cold tail fill the gaps at the end.
 template <typename S, int TILE>
 __global__ void __launch_bounds__(PRC_THREADS)
-pr_cold_pair_kernel(const prc_item1* __restrict__ items, int n_items, unsigned int* __restrict__ queue,
+pr_cold_tile_kernel(const prc_item1* __restrict__ items, int n_items, unsigned int* __restrict__ queue,
                     const S* __restrict__ contrib, const int32_t* __restrict__ org, int nranks, int64_t span, int64_t slice, int64_t T,
                     const uint16_t* __restrict__ srcl, const int32_t* __restrict__ ob, S* __restrict__ val, unsigned sink_base) {
     __shared__ S s_tile[TILE];
@@ -493,7 +576,6 @@ pr_cold_pair_kernel(const prc_item1* __restrict__ items, int n_items, unsigned i
     __shared__ int s_item;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    S* stage = s_stage[wv];
     const unsigned sink = sink_base + (blockIdx.x * PRC_WAVES + wv) * 64 + lane;   // where a lane's idle stores go
     int loaded = -1;
     for (;;) {
@@ -503,104 +585,13 @@ pr_cold_pair_kernel(const prc_item1* __restrict__ items, int n_items, unsigned i
         const int it = s_item;
         if (it >= n_items) break;
         const prc_item1 d = items[it];
-        const int nsuper = (d.g1 - d.g0) / PRC_SUPER_GROUPS;
-        // 8 entries per lane; block b of the item starts 64 vectors (16 groups) after block b - 1
-        const prc_u32x4* in = (const prc_u32x4*) srcl + ((int64_t) d.g0 * (PRC_G / 8) + wv * 64 + lane);
-        const int32_t* obp = ob + (d.g0 + wv * PRC_BLK_GROUPS + (lane >> 2));
-        constexpr int64_t IN_STEP = PRC_PAIR_DEPTH * PRC_WAVES * 64;
-        constexpr int64_t OB_STEP = PRC_PAIR_DEPTH * PRC_WAVES * PRC_BLK_GROUPS;
         if (d.tile != loaded) {   // (workgroup-uniform) chunks of one tile often follow each other
             prc_load_tile<S, TILE>(s_tile, d.tile, org, contrib, nranks, span, slice, T);
             loaded = d.tile;
             __syncthreads();
         }
-        prc_set A, B;
-#define PRC_PROCESS(t)                                                    \
-    do {                                                                  \
-        prc_pair_block<S>(s_tile, stage, (t).e0, (t).o0, val, sink, lane); \
-        prc_pair_block<S>(s_tile, stage, (t).e1, (t).o1, val, sink, lane); \
-        prc_pair_block<S>(s_tile, stage, (t).e2, (t).o2, val, sink, lane); \
-        prc_pair_block<S>(s_tile, stage, (t).e3, (t).o3, val, sink, lane); \
-    } while (0)
-        // super-step 0 (set A): only the loads of super-step 1 are younger
-        prc_set_load(A, in, obp);
-        {
-            const int kn = 1 < nsuper ? 1 : 0;
-            prc_set_load(B, in + kn * IN_STEP, obp + kn * OB_STEP);
-        }
-        PRC_SET_WAIT(A, 8);
-        PRC_PROCESS(A);
-        int k = 1;
-#pragma unroll 1
-        for (; k + 1 < nsuper; k += 2) {
-            prc_set_load(A, in + (int64_t) (k + 1) * IN_STEP, obp + (int64_t) (k + 1) * OB_STEP);
-            PRC_SET_WAIT(B, 40);   // 32 stores of the previous super-step + the 8 loads just issued
-            PRC_PROCESS(B);
-            const int kn = k + 2 < nsuper ? k + 2 : k + 1;
-            prc_set_load(B, in + (int64_t) kn * IN_STEP, obp + (int64_t) kn * OB_STEP);
-            PRC_SET_WAIT(A, 40);
-            PRC_PROCESS(A);
-        }
-        if (k < nsuper) {   // one super-step left, in B; nothing younger than the stores of the previous one
-            PRC_SET_WAIT(B, 32);
-            PRC_PROCESS(B);
-        } else {
-            PRC_SET_WAIT(B, 0);   // the redundant prefetch of the last super-step: land before B is loaded again
-        }
-#undef PRC_PROCESS
-    }
-}
-
-// Phase 1, edge form: every entry is an item.  A lane handles 4 consecutive entries of one group: one 8-byte load,
-// four LDS reads, one 16/32-byte store; 8 lanes cover a group, a wave 8 groups ("piece") per instruction.
-template <typename S, int TILE>
-__global__ void __launch_bounds__(PRC_THREADS)
-pr_cold_gather_kernel(const prc_item1* __restrict__ items, int n_items, unsigned int* __restrict__ queue,
-                      const S* __restrict__ contrib, const int32_t* __restrict__ org, int nranks, int64_t span, int64_t slice, int64_t T,
-                      const uint16_t* __restrict__ srcl, const int32_t* __restrict__ ob, S* __restrict__ val) {
-    typedef typename prc_vec4<S>::type V4;
-    __shared__ S s_tile[TILE];
-    __shared__ int s_item;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int loaded = -1;
-    for (;;) {
-        __syncthreads();   // everybody is done with s_item and the tile of the previous item
-        if (tid == 0) s_item = (int) atomicAdd(&queue[PRC_Q1E], 1u);
-        __syncthreads();
-        const int it = s_item;
-        if (it >= n_items) break;
-        const prc_item1 d = items[it];
-        if (d.tile != loaded) {
-            prc_load_tile<S, TILE>(s_tile, d.tile, org, contrib, nranks, span, slice, T);
-            loaded = d.tile;
-            __syncthreads();
-        }
-        const int npieces = (d.g1 - d.g0 + 7) >> 3;
-        for (int base = 0; base < npieces; base += PRC_WAVES * PRC_UNROLL) {
-            prc_u32x2 ids[PRC_UNROLL];
-            int32_t o[PRC_UNROLL];
-#pragma unroll
-            for (int u = 0; u < PRC_UNROLL; u++) {
-                const int pc = base + u * PRC_WAVES + wv;
-                const int g = d.g0 + pc * 8 + (lane >> 3);
-                o[u] = -1;
-                if (pc < npieces && g < d.g1) {
-                    ids[u] = __builtin_nontemporal_load((const prc_u32x2*) srcl + (int64_t) g * (PRC_G / 4) + (lane & 7));
-                    o[u] = __builtin_nontemporal_load(ob + g);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < PRC_UNROLL; u++) {
-                if (o[u] < 0) continue;
-                V4 v;
-                v.x = s_tile[ids[u].x & 0x7fffu];
-                v.y = s_tile[(ids[u].x >> 16) & 0x7fffu];
-                v.z = s_tile[ids[u].y & 0x7fffu];
-                v.w = s_tile[(ids[u].y >> 16) & 0x7fffu];
-                __builtin_nontemporal_store(v, (V4*) (val + o[u]) + (lane & 7));   // o is a multiple of G: aligned lines
-            }
-        }
+        if (d.form) prc_pair_item<S>(d, s_tile, s_stage[wv], srcl, ob, val, sink, wv, lane);
+        else prc_edge_item<S>(d, s_tile, srcl, ob, val, wv, lane);
     }
 }
 
@@ -1002,14 +993,19 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
     }
     // ---- work lists ----
     {
-        const int ch1 = std::max(PRC_SUPER_GROUPS, prc_env_int("GMX_PR_COLD_CHUNK1", 8192)) / PRC_SUPER_GROUPS * PRC_SUPER_GROUPS;   // groups per phase-1 item
-        const int ch2 = std::max(8, prc_env_int("GMX_PR_COLD_CHUNK", 32768)) / 8 * 8;   // groups per phase-2 item (1 Mi items): only hub bins are split
+        // Work item sizes: about four items per CU (an item costs a tile copy / an accumulator flush and a few
+        // barriers: RMAT-26 fp32 runs 1.74 ms per iteration with 32 Ki-group items, 1.84 with 8 Ki, 2.06 with 2 Ki),
+        // at most 1 Mi entries; phase 2 then only splits the hub bins (every split costs 128 KiB of accumulators
+        // written and read again).
+        const int64_t want1 = ngroups1 / ((int64_t) c->grid * 4), want2 = ngroups2 / ((int64_t) c->grid * 2);
+        const int ch1 = (int) std::min<int64_t>(32768, std::max<int64_t>(PRC_SUPER_GROUPS, prc_env_int("GMX_PR_COLD_CHUNK1", (int) std::min<int64_t>(want1, 32768)))) / PRC_SUPER_GROUPS * PRC_SUPER_GROUPS;
+        const int ch2 = (int) std::min<int64_t>(32768, std::max<int64_t>(8, prc_env_int("GMX_PR_COLD_CHUNK", (int) std::min<int64_t>(std::max<int64_t>(want2, 2048), 32768)))) / 8 * 8;
         for (int64_t t = 0; t < c->ntiles; t++) {
             const int32_t g0 = tstart[t];
             // pair tiles run whole blocks (the padding behind the last cell ends no pair); edge tiles stop at the
             // last real group (an entry there would be stored)
             const int32_t g1 = hmode[t] ? tstart[t + 1] : g0 + (ht[4 * (t + 1) + 1] - ht[4 * t + 1]);
-            for (int32_t g = g0; g < g1; g += ch1) (hmode[t] ? v1p : v1e).push_back({(int32_t) t, g, std::min(g1, g + ch1), 0});
+            for (int32_t g = g0; g < g1; g += ch1) (hmode[t] ? v1p : v1e).push_back({(int32_t) t, g, std::min(g1, g + ch1), hmode[t] ? 1 : 0});
         }
         int32_t slot = 0;
         c->all_bins = true;
@@ -1031,15 +1027,14 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
         c->n2 = (int64_t) v2.size();
         c->n3 = (int64_t) v3.size();
         c->nslots = slot;
+        v1p.insert(v1p.end(), v1e.begin(), v1e.end());   // one queue: pair items, then the edge items
         PRC_ALLOC(c->it1p, std::max<size_t>(1, v1p.size()));
-        PRC_ALLOC(c->it1e, std::max<size_t>(1, v1e.size()));
         PRC_ALLOC(c->it2, std::max<size_t>(1, v2.size()));
         PRC_ALLOC(c->it3, std::max<size_t>(1, v3.size()));
         PRC_ALLOC(c->scratch, std::max<size_t>(1, (size_t) slot * c->limbs * c->binrows));
         PRC_ALLOC(c->diffp, std::max<size_t>(1, v2.size() + v3.size() * (size_t) (c->binrows / 64)));
         PRC_TRY(hipMemset(c->diffp.p, 0, sizeof(double) * std::max<size_t>(1, v2.size() + v3.size() * (size_t) (c->binrows / 64))), "memset");
         if (!v1p.empty()) PRC_TRY(hipMemcpy(c->it1p.p, v1p.data(), sizeof(prc_item1) * v1p.size(), hipMemcpyHostToDevice), "copy");
-        if (!v1e.empty()) PRC_TRY(hipMemcpy(c->it1e.p, v1e.data(), sizeof(prc_item1) * v1e.size(), hipMemcpyHostToDevice), "copy");
         if (!v2.empty()) PRC_TRY(hipMemcpy(c->it2.p, v2.data(), sizeof(prc_item2) * v2.size(), hipMemcpyHostToDevice), "copy");
         if (!v3.empty()) PRC_TRY(hipMemcpy(c->it3.p, v3.data(), sizeof(prc_item3) * v3.size(), hipMemcpyHostToDevice), "copy");
     }
@@ -1086,14 +1081,10 @@ static void prc_launch(pr_cold* c, const void* contrib, const pr_cold_fuse& fz, 
     const double lo_scale = ldexp(1.0, c->lo_bits);
     const int64_t span = c->prm.slice - c->prm.T;
     (void) hipMemsetAsync(c->queue.p, 0, 3 * 64 * sizeof(unsigned int), s);
-    if (c->n1p > 0)
-        hipLaunchKernelGGL((pr_cold_pair_kernel<S, TILE>), dim3((unsigned) std::min<int64_t>(c->grid, c->n1p)), dim3(PRC_THREADS), 0, s,
-                           (const prc_item1*) c->it1p.p, (int) c->n1p, c->queue.p, (const S*) contrib, (const int32_t*) c->torg.p, c->prm.nranks, span, c->prm.slice,
+    if (c->n1p + c->n1e > 0)
+        hipLaunchKernelGGL((pr_cold_tile_kernel<S, TILE>), dim3((unsigned) std::min<int64_t>(c->grid, c->n1p + c->n1e)), dim3(PRC_THREADS), 0, s,
+                           (const prc_item1*) c->it1p.p, (int) (c->n1p + c->n1e), c->queue.p, (const S*) contrib, (const int32_t*) c->torg.p, c->prm.nranks, span, c->prm.slice,
                            c->prm.T, (const uint16_t*) c->srcl.p, (const int32_t*) c->ob.p, (S*) c->val.p, (unsigned) c->P2);
-    if (c->n1e > 0)
-        hipLaunchKernelGGL((pr_cold_gather_kernel<S, TILE>), dim3((unsigned) std::min<int64_t>(c->grid, c->n1e)), dim3(PRC_THREADS), 0, s,
-                           (const prc_item1*) c->it1e.p, (int) c->n1e, c->queue.p, (const S*) contrib, (const int32_t*) c->torg.p, c->prm.nranks, span, c->prm.slice,
-                           c->prm.T, (const uint16_t*) c->srcl.p, (const int32_t*) c->ob.p, (S*) c->val.p);
     hipLaunchKernelGGL((pr_cold_accum_kernel<S, BINROWS, LIMBS, FUSE>), dim3((unsigned) std::min<int64_t>(c->grid, c->n2)), dim3(PRC_THREADS), 0, s,
                        (const prc_item2*) c->it2.p, (int) c->n2, c->queue.p, (const uint16_t*) c->rowl.p, (const S*) c->val.p,
                        c->prm.nactive, lo_scale, (S*) c->cold.p, c->scratch.p, fz, c->diffp.p);
