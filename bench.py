@@ -12,13 +12,22 @@ The graph is the reference's own RMAT generator (graph_gen.cc:159-287, seed 1997
 .57,.19,.19, edge factor 16, permute=true) run on the device, then do_semi_sort +
 make_reverse_edges exactly as load_binary does.  Total work is fixed as N grows ("strong").
 
-Rank 0 prints ONE JSON line with the driver's contract fields plus `roofline` and `cpu_baseline`.
+Rank 0 prints ONE JSON line with the driver's contract fields plus `roofline`, `cpu_baseline` and, at N = 1,
+`extra`: the other BASELINE.json configurations measured in the same run (PageRank fp64 on the same graph,
+PageRank fp32 on RMAT-24, hop_dist from vertex 0 on RMAT-26, triangle counting on symmetrised RMAT-24).
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
+
+# the CPU baseline pins its OpenMP threads like the reference's run.sh does (scripts/run.sh:237-238,350);
+# libgomp reads this once, when it is first loaded
+os.environ.setdefault("GOMP_CPU_AFFINITY", "0-%d" % ((os.cpu_count() or 1) - 1))
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "green-marl_amd"))
@@ -26,24 +35,90 @@ sys.path.insert(0, os.path.join(ROOT, "green-marl_amd"))
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def cpu_baseline(gmx, scale, iters):
-    """The oracle's OpenMP restatement of the emitted pagerank (kind "port"), timed on this box's
-    host cores on a bounded sample of the same workload.  The checker is only TIMED here; nothing
-    it computes feeds the GPU path."""
+def kernel_code_hash():
+    """sha256 over the HIP sources: a PMC traffic figure is only quoted for the code it was measured on."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "green-marl_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(gmx, graph, scale):
+    """The oracle's OpenMP restatement of the emitted pagerank (kind "port") on the SAME graph the GPU line is
+    measured on, on this box's host cores: one warm-up iteration, then the median of three single iterations
+    (BASELINE.md section 2).  The checker is only TIMED here; nothing it computes feeds the GPU path."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
-    g = gmx.Graph.rmat(1 << scale, 16 << scale, 1997, 0.57, 0.19, 0.19, True)
-    begin, node_idx, rb, rn = g.download()
-    g.free()
-    og = po.Graph(1 << scale, begin, node_idx, rb, rn)
+    begin, node_idx, rb, rn = graph.download()
+    og = po.Graph(graph.V, begin, node_idx, rb, rn)
     cores = po.lib().gmo_max_threads()
     po.pagerank(og, 1e-300, 0.85, 1, nthreads=cores)     # touch pages / warm up
-    t0 = time.perf_counter()
-    _, it, _ = po.pagerank(og, 1e-300, 0.85, iters, nthreads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": og.M * it / dt / 1e9, "unit": "GTEPS", "cores": cores, "kind": "port",
-            "sample": "RMAT-%d (same generator, seed, permute), %d iterations of the fp64 OpenMP restatement "
-                      "of the emitted pagerank loop (schedule(dynamic,128)), %.1f s" % (scale, it, dt)}
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        po.pagerank(og, 1e-300, 0.85, 1, nthreads=cores)
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
+    return {"value": og.M / dt / 1e9, "unit": "GTEPS", "cores": cores, "kind": "port",
+            "sample": "the bench graph itself (RMAT-%d, E=%d): 1 warm-up + 3 single iterations of the fp64 OpenMP "
+                      "restatement of the emitted pagerank loop (schedule(dynamic,128)), median %.2f s per iteration "
+                      "(%.2f / %.2f / %.2f), GOMP_CPU_AFFINITY=%s" % (scale, og.M, dt, times[0], times[1], times[2],
+                                                                   os.environ.get("GOMP_CPU_AFFINITY", ""))}
+
+
+def pagerank_steps(gmx, graph, elem, steps, warmup):
+    """ms per iteration of the stepping API on one GPU (hipEvents around every step's kernels)."""
+    st = gmx.PageRankState(graph, elem, 0, 1, gmx.default_pr_options(graph.V, 1))
+    st.reset(0.85)
+    for _ in range(warmup):
+        st.step()
+    st.timing(True)
+    for _ in range(steps):
+        st.step()
+    n, ms = st.kernel_time()
+    work = st.work()
+    st.free()
+    return {"ms_per_iter": ms, "gteps": graph.E / (ms * 1e-3) / 1e9,
+            "roofline_frac": work["algorithmic_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "iterations_timed": n}
+
+
+def extras(gmx, graph26, scale):
+    """The other BASELINE.json configurations, measured in this run (1 GPU)."""
+    out = {}
+    out["pagerank_f64_rmat%d" % scale] = dict(pagerank_steps(gmx, graph26, 8, 10, 3),
+                                               note="same graph as the headline, Node_Prop<Double> (the reference's signature); "
+                                                    "algorithmic bytes 12E + 32V")
+    g24 = gmx.Graph.rmat(1 << 24, 16 << 24, 1997, 0.57, 0.19, 0.19, True)
+    out["pagerank_f32_rmat24"] = dict(pagerank_steps(gmx, g24, 4, 20, 3), note="BASELINE configs[1]; algorithmic bytes 8E + 20V")
+    # triangle counting on the symmetrised simple version of the same RMAT-24 (SURVEY.md 8d)
+    gs = g24.symmetrize()
+    g24.free()
+    T, st = gs.triangle_counting()
+    T2, st2 = gs.triangle_counting()            # second call: the degree-ordered copy is cached, like the reverse CSR
+    out["triangle_counting_rmat24_sym"] = {"seconds": st2["kernel_ms"] * 1e-3, "first_call_seconds": st["kernel_ms"] * 1e-3,
+                                            "triangles": T, "edges": gs.E, "gteps": gs.E / (st2["kernel_ms"] * 1e-3) / 1e9,
+                                            "note": "BASELINE configs[4]; E = edge slots of the symmetrised graph"}
+    assert T == T2
+    gs.free()
+    # hop_dist from vertex 0 on RMAT-26 without the final permutation (vertex 0 is then the top hub; with
+    # permute=true vertex 0 may be isolated, SURVEY.md section 7)
+    gb = gmx.Graph.rmat(1 << scale, 16 << scale, 1997, 0.57, 0.19, 0.19, False)
+    runs = []
+    for _ in range(4):
+        _, st = gb.hop_dist(0)
+        runs.append(st)
+    st = sorted(runs[1:], key=lambda r: r["kernel_ms"])[1]
+    t = st["kernel_ms"] * 1e-3
+    out["hop_dist_rmat%d_root0" % scale] = {
+        "ms": st["kernel_ms"], "levels": st["iterations"], "vertices_reached": st["vertices_reached"],
+        "edges_reached": st["edges_reached"], "edges_examined": st["edges_examined"],
+        "gteps": st["edges_reached"] / t / 1e9,
+        "roofline_frac": (8 * st["edges_reached"] + 12 * st["vertices_reached"]) / t / 1e9 / HBM_PEAK_GBS,
+        "note": "BASELINE configs[2]; median of 3 warm traversals; TEPS in the Graph500 convention (out-edges of the reached "
+                "vertices / time); algorithmic bytes 8 E_r + 12 V_r -- direction optimisation examines fewer edges"}
+    gb.free()
+    return out
 
 
 def main():
@@ -58,9 +133,8 @@ def main():
     ap.add_argument("--chunks", type=int, default=0, help="row chunks per step for N > 1 (0: 2 when the sliced variant runs)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "push", "collective"],
                     help="N > 1: peer copies over xGMI (hipIpc + copy engines) or RCCL all-gather; auto = push if it sets up")
-    ap.add_argument("--cpu-scale", type=int, default=24)
-    ap.add_argument("--cpu-iters", type=int, default=30)
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configurations")
     args = ap.parse_args()
 
     # Keep stdout clean for the ONE JSON line: libraries (RCCL prints a version banner to stdout) are
@@ -94,10 +168,6 @@ def main():
     elem = 4 if args.dtype == "f32" else 8
     options = gmx.default_pr_options(1 << args.scale, world) if args.options < 0 else args.options
     N, M = 1 << args.scale, args.edge_factor << args.scale
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(gmx, args.cpu_scale, args.cpu_iters)
 
     t0 = time.perf_counter()
     graph = gmx.Graph.rmat(N, M, 1997, 0.57, 0.19, 0.19, True)
@@ -140,14 +210,29 @@ def main():
     gteps = graph.E / (ms_per_step * 1e-3) / 1e9
     achieved = work["algorithmic_bytes"] / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
 
-    # HBM bytes per step measured offline with rocprofv3 --pmc on this same command (committed under profiles/)
-    traffic = None
+    # HBM bytes per step measured offline with rocprofv3 --pmc on this same command (committed under profiles/):
+    # quoted only while the kernel sources are the ones it was measured on
+    traffic, traffic_source = None, None
+    code_hash = kernel_code_hash()
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "bench_traffic.json")))
-        if args.edge_factor == 16:
-            traffic = tj.get("scale%d_%s_opt%d_gpus%d" % (args.scale, args.dtype, options, world))
+        ent = tj.get("scale%d_%s_opt%d_gpus%d" % (args.scale, args.dtype, options, world)) if args.edge_factor == 16 else None
+        if isinstance(ent, dict) and ent.get("kernel_code_hash") == code_hash:
+            traffic, traffic_source = ent["hbm_bytes_per_step"], ent.get("source")
+        elif isinstance(ent, dict):
+            traffic_source = "stale: %s was measured at kernel code %s, this is %s" % (ent.get("source"), ent.get("kernel_code_hash"), code_hash)
     except (OSError, ValueError):
         pass
+
+    kernel_name = engine.state.kernel_name()
+    cpu = extra = copy_gbs = None
+    if rank == 0 and world == 1:
+        engine.state.free()   # make room: the extras build their own plans
+        copy_gbs = gmx.copy_bandwidth(1 << 30, 10)
+        if not args.no_extra and args.edge_factor == 16:
+            extra = extras(gmx, graph, args.scale)
+        if not args.no_cpu:
+            cpu = cpu_baseline(gmx, graph, args.scale)
 
     if rank == 0:
         out = {
@@ -163,10 +248,13 @@ def main():
                                     if pr.exchange == "push" else "RCCL all-gather of contribution slices, %d row chunk(s)") % chunks,
                        "options": options, "setup_s": round(setup_s, 2), "last_diff": last_diff},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": engine.state.kernel_name(), "kernel_ms": kernel_ms, "launches": launches,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "copy_bw_gbs": copy_gbs, "frac_of_copy": (achieved / copy_gbs) if copy_gbs else None,
+                         "kernel_code_hash": code_hash,
+                         "kernel": kernel_name, "kernel_ms": kernel_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": work["algorithmic_bytes"]},
             "cpu_baseline": cpu,
+            "extra": extra,
         }
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())

@@ -62,6 +62,39 @@ extern "C" int gmx_device_info(gmx_device_info_t* info) {
     return GMX_OK;
 }
 
+// Device copy bandwidth: the measured ceiling next to the 8 TB/s data-sheet figure (SURVEY.md 8d asks for both).
+typedef float gmx_f32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) copy_f32x4_kernel(const gmx_f32x4* __restrict__ src, gmx_f32x4* __restrict__ dst, int64_t n) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
+extern "C" int gmx_copy_bandwidth(int64_t bytes, int iters, double* gbs) {
+    GMX_REQUIRE(gbs && bytes >= 4096 && iters >= 1, "bad argument");
+    const int64_t n = bytes / 16;
+    dbuf<gmx_f32x4> a, b;
+    GMX_CHECK(a.alloc((size_t) n));
+    GMX_CHECK(b.alloc((size_t) n));
+    GMX_HIP(hipMemset(a.p, 1, (size_t) n * 16));
+    hipEvent_t e0, e1;
+    GMX_HIP(hipEventCreate(&e0));
+    GMX_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(copy_f32x4_kernel, dim3(256 * 8), dim3(256), 0, 0, (const gmx_f32x4*) a.p, b.p, n);   // warm-up
+    (void) hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; i++)
+        hipLaunchKernelGGL(copy_f32x4_kernel, dim3(256 * 8), dim3(256), 0, 0, (const gmx_f32x4*) a.p, b.p, n);
+    (void) hipEventRecord(e1, 0);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void) hipEventDestroy(e0);
+    (void) hipEventDestroy(e1);
+    GMX_HIP(e);
+    *gbs = 2.0 * (double) n * 16.0 * iters / (ms * 1e-3) / 1e9;   // bytes read + bytes written
+    return GMX_OK;
+}
+
 // ------------------------------------------------------------------ keys <-> CSR
 // key = (row << 32 | col); 2^31 vertices max (node_t is int32).
 __global__ void keys_from_csr_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ idx,

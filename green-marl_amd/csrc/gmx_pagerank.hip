@@ -1865,16 +1865,24 @@ extern "C" int gmx_pr_download(gmx_pr_t* p, void* rank_host) {
     return GMX_OK;
 }
 
-// Variant choice by size (measured on RMAT, edge factor 16, fp32; ms per iteration plain / LDS tile / sliced):
-// 2^16: 0.018 / 0.028 / 0.056   2^18: 0.033 / 0.041 / 0.084   2^19: 0.058 / 0.055 / 0.090
-// 2^20: 0.097 / 0.085 / 0.115   2^21: 0.196 / 0.156 / 0.152    2^22 and up: sliced (RMAT-24: 1.01 vs 1.53 ms).
+// Variant choice by size (measured on RMAT, edge factor 16, fp32; ms per iteration):
+//          plain   LDS tile  sliced pull  binned (tile-gather / bin-accumulate, gmx_pr_cold.hip)
+// 2^16     0.018   0.028     0.056
+// 2^18     0.033   0.041     0.084
+// 2^19     0.060   0.057     0.090        0.068
+// 2^20     0.098   0.086     0.115        0.083
+// 2^21     0.197   0.156     0.152        0.121
+// 2^22                       0.264        0.177
+// 2^24                       1.04         0.49
+// 2^26                       4.80         1.70
 // Up to 2^18 vertices the whole contribution vector sits in every L2 and filling an LDS tile per launch costs
-// more than it saves; up to 2^21 the unsliced kernel with the tile wins; beyond, splitting the sources over
-// the XCD L2s pays for its partial-sum pass.
+// more than it saves; up to 2^20 the unsliced kernel with the tile wins; beyond, every edge goes through the
+// bins (GMX_PR_SLICED only provides the row bookkeeping they share with the sliced pull sweep, which remains
+// reachable by leaving GMX_PR_COLD_PB out).
 extern "C" uint32_t gmx_pr_default_options(int64_t V, int nranks) {
     uint32_t o = GMX_PR_RELABEL;
     if (V > (1LL << 18)) o |= GMX_PR_HOT_LDS;   // with several ranks the tile is only used by the sliced kernel
-    if (V > (1LL << 21)) o |= GMX_PR_SLICED | GMX_PR_COLD_PB;   // the cold part only exists past ~3.5 M vertices per rank
+    if (V > (1LL << 20)) o |= GMX_PR_SLICED | GMX_PR_COLD_PB;
     return o;
 }
 

@@ -41,7 +41,7 @@ class DeviceInfo(C.Structure):
 
 
 EXPORTS = [
-    "gmx_last_error", "gmx_device_count", "gmx_set_device", "gmx_device_info",
+    "gmx_last_error", "gmx_device_count", "gmx_set_device", "gmx_device_info", "gmx_copy_bandwidth",
     "gmx_graph_upload", "gmx_graph_from_edges", "gmx_graph_create_rmat", "gmx_graph_free", "gmx_graph_symmetrize",
     "gmx_graph_num_nodes", "gmx_graph_num_edges", "gmx_graph_download",
     "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_sssp", "gmx_avg_teen_cnt", "gmx_conduct", "gmx_triangle_counting", "gmx_triangle_counting_part", "gmx_graph_reverse_edge_map",
@@ -78,6 +78,7 @@ def lib():
         L.gmx_device_count.argtypes = [C.POINTER(C.c_int)]
         L.gmx_set_device.argtypes = [C.c_int]
         L.gmx_device_info.argtypes = [C.POINTER(DeviceInfo)]
+        L.gmx_copy_bandwidth.argtypes = [i64, C.c_int, C.POINTER(C.c_double)]
         L.gmx_graph_upload.argtypes = [vp, vp, vp, vp, i64, i64, C.c_uint32, C.POINTER(vp)]
         L.gmx_graph_from_edges.argtypes = [vp, vp, i64, i64, C.c_uint32, C.POINTER(vp)]
         L.gmx_graph_create_rmat.argtypes = [i64, i64, C.c_long, C.c_double, C.c_double, C.c_double, C.c_int,
@@ -166,6 +167,13 @@ def device_info():
     return {"name": d.name.decode(), "arch": d.arch.decode(), "compute_units": d.compute_units,
             "clock_mhz": d.clock_mhz, "hbm_bytes": d.hbm_bytes, "l2_bytes": d.l2_bytes,
             "lds_bytes_per_cu": d.lds_bytes_per_cu}
+
+
+def copy_bandwidth(nbytes=1 << 30, iters=10):
+    """Measured device copy rate in GB/s (bytes read + written)."""
+    g = C.c_double(0)
+    _ck(lib().gmx_copy_bandwidth(nbytes, iters, C.byref(g)))
+    return g.value
 
 
 def _i32(a):

@@ -16,7 +16,7 @@ steps = int(os.environ.get("SWEEP_STEPS", "10"))
 gmx.require_device()
 gmx.set_device(0)
 g = gmx.Graph.rmat(1 << scale, 16 << scale, 1997, 0.57, 0.19, 0.19, True)
-base = gmx.default_pr_options(1 << scale, 1)
+base = int(os.environ.get("SWEEP_OPTIONS", gmx.default_pr_options(1 << scale, 1)))
 for hot in hots:
     opts = base
     if hot < 0:

@@ -58,6 +58,9 @@ typedef struct {
     int32_t  lds_bytes_per_cu;
 } gmx_device_info_t;
 int gmx_device_info(gmx_device_info_t* info);
+/* Measured device-to-device copy rate (GB/s, bytes read + bytes written) of a `bytes`-sized buffer, `iters` copies:
+ * the achievable HBM ceiling bench.py reports next to the data-sheet peak. */
+int gmx_copy_bandwidth(int64_t bytes, int iters, double* gbs);
 
 /* ---- graph: replaces the emitted prologue `G.freeze(); G.make_reverse_edges();
  *      [G.do_semi_sort();]` + Shoal copy-in (gm_cpp_gen.cc:1307-1368, 670-778) ---- */
