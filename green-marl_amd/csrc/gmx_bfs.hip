@@ -575,6 +575,26 @@ __global__ void sssp_init_kernel(int32_t* __restrict__ dist, int32_t* __restrict
     }
 }
 
+// hipEvents / pinned words that are released on every return path
+struct ev_guard {
+    hipEvent_t e = nullptr;
+    ~ev_guard() { if (e) (void) hipEventDestroy(e); }
+    int create() { GMX_HIP(hipEventCreate(&e)); return GMX_OK; }
+};
+template <typename T>
+struct pinned_guard {
+    T* p = nullptr;
+    ~pinned_guard() { if (p) (void) hipHostFree(p); }
+    int alloc() { GMX_HIP(hipHostMalloc((void**) &p, sizeof(T), hipHostMallocDefault)); return GMX_OK; }
+};
+
+// dst[j] = src[order[j]]: an edge property given by uploaded slot, brought into the order of the sorted rows
+__global__ void gather_by_order_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ order, int64_t n, int32_t* __restrict__ dst) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = src[order[i]];
+}
+
 extern "C" int gmx_sssp(gmx_graph_t* g, gmx_node_t root, const int32_t* len_host, int32_t* dist_host, gmx_stats_t* stats) {
     GMX_REQUIRE(g && dist_host, "NULL argument");
     GMX_REQUIRE(len_host || g->E == 0, "len is NULL");
@@ -597,10 +617,22 @@ extern "C" int gmx_sssp(gmx_graph_t* g, gmx_node_t root, const int32_t* len_host
     GMX_CHECK(len.alloc((size_t) (g->E ? g->E : 1)));
     GMX_HIP(rocprim::inclusive_scan(nullptr, scan_bytes, deg.p, off.p + 1, (size_t) V, rocprim::plus<int64_t>(), 0));
     GMX_CHECK(scan_tmp.alloc(scan_bytes));
+    ev_guard evg[4];
     hipEvent_t ev[4];
-    for (hipEvent_t& e : ev) GMX_HIP(hipEventCreate(&e));
+    for (int i = 0; i < 4; i++) {
+        GMX_CHECK(evg[i].create());
+        ev[i] = evg[i].e;
+    }
     GMX_HIP(hipEventRecord(ev[2], 0));
     if (g->E) GMX_HIP(hipMemcpy(len.p, len_host, sizeof(int32_t) * (size_t) g->E, hipMemcpyHostToDevice));   // the property is the caller's
+    dbuf<int32_t> len_sorted;
+    if (g->E && g->e_idx2idx.p) {
+        // the rows were sorted on upload: len[] is indexed by the caller's (unsorted) slots, the kernel walks the sorted ones
+        GMX_CHECK(len_sorted.alloc((size_t) g->E));
+        hipLaunchKernelGGL(gather_by_order_kernel, dim3(grid_for(g->E)), dim3(BFS_THREADS), 0, 0, (const int32_t*) len.p,
+                           (const int32_t*) g->e_idx2idx.p, g->E, len_sorted.p);
+    }
+    const int32_t* len_dev = len_sorted.p ? len_sorted.p : len.p;
     GMX_HIP(hipEventRecord(ev[3], 0));
     GMX_HIP(hipEventRecord(ev[0], 0));
     hipLaunchKernelGGL(sssp_init_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, dist.p, stamp.p, V, root_ok ? root : -1);
@@ -614,10 +646,12 @@ extern "C" int gmx_sssp(gmx_graph_t* g, gmx_node_t root, const int32_t* len_host
         cur_count = 1;
     }
     // per-round read-backs through pinned memory (two host round trips per round, dozens of rounds)
-    bfs_counters* h_ctr = nullptr;
-    int64_t* h_mf = nullptr;
-    GMX_HIP(hipHostMalloc((void**) &h_ctr, sizeof(bfs_counters), hipHostMallocDefault));
-    GMX_HIP(hipHostMalloc((void**) &h_mf, sizeof(int64_t), hipHostMallocDefault));
+    pinned_guard<bfs_counters> pg_ctr;
+    pinned_guard<int64_t> pg_mf;
+    GMX_CHECK(pg_ctr.alloc());
+    GMX_CHECK(pg_mf.alloc());
+    bfs_counters* h_ctr = pg_ctr.p;
+    int64_t* h_mf = pg_mf.p;
     GMX_HIP(hipMemsetAsync(ctr.p, 0, sizeof(bfs_counters), 0));
     while (cur_count > 0) {
         GMX_HIP(hipMemsetAsync(&ctr.p->next_count, 0, sizeof(unsigned long long), 0));   // `edges` keeps accumulating
@@ -631,7 +665,7 @@ extern "C" int gmx_sssp(gmx_graph_t* g, gmx_node_t root, const int32_t* len_host
         const int64_t nb = (cur_count + m_f + BFS_ITEMS - 1) / BFS_ITEMS;
         if (nb > 0)
             hipLaunchKernelGGL(sssp_relax_kernel, dim3((unsigned) nb), dim3(BFS_THREADS), 0, 0, g->begin.p, g->node_idx.p,
-                               (const int32_t*) len.p, cur_q, cur_count, off.p, m_f, round, dist.p, stamp.p, next_q, ctr.p);
+                               len_dev, cur_q, cur_count, off.p, m_f, round, dist.p, stamp.p, next_q, ctr.p);
         GMX_HIP(hipGetLastError());
         GMX_HIP(hipMemcpyAsync(h_ctr, ctr.p, sizeof(bfs_counters), hipMemcpyDeviceToHost, 0));
         GMX_HIP(hipStreamSynchronize(0));
@@ -646,8 +680,6 @@ extern "C" int gmx_sssp(gmx_graph_t* g, gmx_node_t root, const int32_t* len_host
     }
     GMX_HIP(hipEventRecord(ev[1], 0));
     GMX_HIP(hipEventSynchronize(ev[1]));
-    (void) hipHostFree(h_ctr);
-    (void) hipHostFree(h_mf);
     GMX_HIP(hipMemcpy(dist_host, dist.p, sizeof(int32_t) * (size_t) V, hipMemcpyDeviceToHost));
     if (stats) {
         float ms = 0, hms = 0;
@@ -659,7 +691,6 @@ extern "C" int gmx_sssp(gmx_graph_t* g, gmx_node_t root, const int32_t* len_host
         stats->edges_examined = (int64_t) edges;
         stats->vertices_reached = requeued + (root_ok ? 1 : 0);   // queue entries over all rounds (a vertex may re-enter)
     }
-    for (hipEvent_t e : ev) (void) hipEventDestroy(e);
     return GMX_OK;
 }
 
@@ -919,8 +950,12 @@ extern "C" int gmx_avg_teen_cnt(gmx_graph_t* g, const int32_t* age_host, int32_t
     GMX_CHECK(age.alloc((size_t) V));
     GMX_CHECK(cnt.alloc((size_t) V));
     GMX_CHECK(acc.alloc(2));
+    ev_guard evg[2];   // released on every return path
     hipEvent_t ev[2];
-    for (hipEvent_t& e : ev) GMX_HIP(hipEventCreate(&e));
+    for (int i = 0; i < 2; i++) {
+        GMX_CHECK(evg[i].create());
+        ev[i] = evg[i].e;
+    }
     GMX_HIP(hipMemcpy(age.p, age_host, sizeof(int32_t) * (size_t) V, hipMemcpyHostToDevice));
     GMX_HIP(hipEventRecord(ev[0], 0));
     GMX_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * (size_t) V, 0));
@@ -952,7 +987,6 @@ extern "C" int gmx_avg_teen_cnt(gmx_graph_t* g, const int32_t* age_host, int32_t
         stats->iterations = 1;
         stats->kernel_ms = ms;
     }
-    for (hipEvent_t e : ev) (void) hipEventDestroy(e);
     return GMX_OK;
 }
 
@@ -962,8 +996,12 @@ extern "C" int gmx_conduct(gmx_graph_t* g, const int32_t* member_host, int32_t n
     *result = 0;
     const int64_t V = g->V;
     unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+    ev_guard evg[2];   // released on every return path
     hipEvent_t ev[2];
-    for (hipEvent_t& e : ev) GMX_HIP(hipEventCreate(&e));
+    for (int i = 0; i < 2; i++) {
+        GMX_CHECK(evg[i].create());
+        ev[i] = evg[i].e;
+    }
     if (V > 0) {
         dbuf<int32_t> member;
         dbuf<unsigned long long> acc;   // [0,1] Din + count, [2,3] Dout + count, [4] Cross
@@ -996,6 +1034,5 @@ extern "C" int gmx_conduct(gmx_graph_t* g, const int32_t* member_host, int32_t n
         stats->iterations = 1;
         stats->kernel_ms = ms;
     }
-    for (hipEvent_t e : ev) (void) hipEventDestroy(e);
     return GMX_OK;
 }

@@ -169,19 +169,47 @@ int gmx_keys_from_edges(const int32_t* src, const int32_t* dst, int64_t E, bool 
     return GMX_OK;
 }
 
+__global__ void iota_i32_kernel(int32_t* __restrict__ p, int64_t n) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = (int32_t) i;
+}
+
+// flag[0] |= 1 if some row of the CSR is not ascending
+__global__ void rows_unsorted_kernel(const uint64_t* __restrict__ keys, int64_t E, int* __restrict__ flag) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    bool bad = false;
+    for (; i < E; i += stride) bad |= keys[i] < keys[i - 1];   // keys are (row << 32 | col) in slot order
+    if (bad) atomicOr(flag, 1);
+}
+
 int gmx_csr_from_keys(uint64_t* keys, uint64_t* keys_alt, int64_t V, int64_t E,
-                      int32_t* begin, int32_t* idx, hipStream_t stream) {
+                      int32_t* begin, int32_t* idx, hipStream_t stream, int32_t* slots) {
     const uint64_t* sorted = keys;
+    dbuf<int32_t> iota;
+    if (slots) {
+        GMX_CHECK(iota.alloc((size_t) (E ? E : 1)));
+        hipLaunchKernelGGL(iota_i32_kernel, dim3(grid_for(E)), dim3(256), 0, stream, E > 1 ? iota.p : slots, E);
+    }
     if (E > 1) {
-        rocprim::double_buffer<uint64_t> db(keys, keys_alt);
-        size_t tmp_bytes = 0;
         unsigned end_bit = 32 + (unsigned) gmx_bits_for(V);
-        GMX_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, db, (size_t) E, 0u, end_bit, stream));
+        size_t tmp_bytes = 0;
         dbuf<char> tmp;
-        GMX_CHECK(tmp.alloc(tmp_bytes));
-        GMX_HIP(rocprim::radix_sort_keys((void*) tmp.p, tmp_bytes, db, (size_t) E, 0u, end_bit, stream));
-        GMX_HIP(hipStreamSynchronize(stream));
-        sorted = db.current();
+        if (slots) {   // stable: equal (row, col) keys keep their input order
+            GMX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_alt, iota.p, slots, (size_t) E, 0u, end_bit, stream));
+            GMX_CHECK(tmp.alloc(tmp_bytes));
+            GMX_HIP(rocprim::radix_sort_pairs((void*) tmp.p, tmp_bytes, keys, keys_alt, iota.p, slots, (size_t) E, 0u, end_bit, stream));
+            GMX_HIP(hipStreamSynchronize(stream));
+            sorted = keys_alt;
+        } else {
+            rocprim::double_buffer<uint64_t> db(keys, keys_alt);
+            GMX_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, db, (size_t) E, 0u, end_bit, stream));
+            GMX_CHECK(tmp.alloc(tmp_bytes));
+            GMX_HIP(rocprim::radix_sort_keys((void*) tmp.p, tmp_bytes, db, (size_t) E, 0u, end_bit, stream));
+            GMX_HIP(hipStreamSynchronize(stream));
+            sorted = db.current();
+        }
     }
     hipLaunchKernelGGL(csr_extract_kernel, dim3(grid_for(E > V ? E : V + 1)), dim3(256), 0, stream,
                        sorted, V, E, begin, idx);
@@ -191,11 +219,24 @@ int gmx_csr_from_keys(uint64_t* keys, uint64_t* keys_alt, int64_t V, int64_t E,
 }
 
 // Build forward (and reverse) CSR of g from device keys (row<<32|col), consuming them.
-static int build_from_forward_keys(gmx_graph* g, dbuf<uint64_t>& keys, dbuf<uint64_t>& alt, bool want_reverse) {
+static int build_from_forward_keys(gmx_graph* g, dbuf<uint64_t>& keys, dbuf<uint64_t>& alt, bool want_reverse, bool keep_order = false) {
     hipStream_t s = 0;
     GMX_CHECK(g->begin.alloc((size_t) g->V + 1));
     GMX_CHECK(g->node_idx.alloc((size_t) g->E));
-    GMX_CHECK(gmx_csr_from_keys(keys.p, alt.p, g->V, g->E, g->begin.p, g->node_idx.p, s));
+    int32_t* slots = nullptr;
+    if (keep_order && g->E > 1) {   // rows out of order: remember where every sorted slot came from (e_idx2idx)
+        dbuf<int> flag;
+        GMX_CHECK(flag.alloc(1));
+        GMX_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), s));
+        hipLaunchKernelGGL(rows_unsorted_kernel, dim3(grid_for(g->E)), dim3(256), 0, s, (const uint64_t*) keys.p, g->E, flag.p);
+        int h = 0;
+        GMX_HIP(hipMemcpy(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (h) {
+            GMX_CHECK(g->e_idx2idx.alloc((size_t) g->E));
+            slots = g->e_idx2idx.p;
+        }
+    }
+    GMX_CHECK(gmx_csr_from_keys(keys.p, alt.p, g->V, g->E, g->begin.p, g->node_idx.p, s, slots));
     if (want_reverse) {
         GMX_CHECK(g->r_begin.alloc((size_t) g->V + 1));
         GMX_CHECK(g->r_node_idx.alloc((size_t) g->E));
@@ -242,7 +283,7 @@ extern "C" int gmx_graph_upload(const gmx_edge_t* begin, const gmx_node_t* node_
                 break;
             }
             if ((st = gmx_keys_from_csr(tb.p, ti.p, V, E, false, nullptr, keys.p, 0))) break;
-            if ((st = build_from_forward_keys(g, keys, alt, want_rev))) break;
+            if ((st = build_from_forward_keys(g, keys, alt, want_rev, (flags & GMX_GRAPH_SORT_ROWS) != 0))) break;
         } else {
             if ((st = g->begin.alloc((size_t) V + 1)) || (st = g->node_idx.alloc((size_t) E))) break;
             if (hipMemcpy(g->begin.p, begin, sizeof(int32_t) * ((size_t) V + 1), hipMemcpyHostToDevice) != hipSuccess ||
@@ -345,7 +386,8 @@ __global__ void rmat_attempts_kernel(lcg_table tab, uint64_t x0, int64_t t_begin
                                      const int64_t* __restrict__ slot_map,
                                      int32_t N, int32_t SCALE, double a, double b, double c, double d,
                                      int32_t* __restrict__ src, int32_t* __restrict__ dst,
-                                     int64_t* __restrict__ bad_slots, unsigned long long* __restrict__ bad_count) {
+                                     int64_t* __restrict__ bad_slots, unsigned long long bad_cap,
+                                     unsigned long long* __restrict__ bad_count) {
     int64_t i0 = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) * ATT_PER_THREAD;
     if (i0 >= count) return;
     // jump to attempt t_begin + i0
@@ -397,7 +439,7 @@ __global__ void rmat_attempts_kernel(lcg_table tab, uint64_t x0, int64_t t_begin
         dst[slot] = v - 1;
         if (u == v) {
             unsigned long long k = atomicAdd(bad_count, 1ULL);
-            bad_slots[k] = slot;
+            if (k < bad_cap) bad_slots[k] = slot;   // past the list's end only the count grows: the host reports the overflow
         }
     }
 }
@@ -446,7 +488,7 @@ extern "C" int gmx_graph_create_rmat(int64_t N, int64_t M, long seed, double a, 
             int64_t blocks = (threads + 255) / 256;
             hipLaunchKernelGGL(rmat_attempts_kernel, dim3((unsigned) blocks), dim3(256), 0, 0,
                                tab, x0, attempts, count, first ? (const int64_t*) nullptr : (const int64_t*) slots.p,
-                               (int32_t) N, SCALE, a, b, c, d, src.p, dst.p, bad.p, nbad.p);
+                               (int32_t) N, SCALE, a, b, c, d, src.p, dst.p, bad.p, (unsigned long long) bad_cap, nbad.p);
             if ((he = hipGetLastError()) != hipSuccess) break;
             unsigned long long nb = 0;
             if ((he = hipMemcpy(&nb, nbad.p, sizeof(nb), hipMemcpyDeviceToHost)) != hipSuccess) break;
@@ -582,6 +624,15 @@ extern "C" int gmx_graph_symmetrize(const gmx_graph_t* g, gmx_graph_t** out) {
 }
 
 // ------------------------------------------------------------------ misc
+extern "C" int gmx_graph_edge_order(const gmx_graph_t* g, gmx_edge_t* e_idx2idx, int* is_identity) {
+    GMX_REQUIRE(g, "graph is NULL");
+    const bool ident = g->e_idx2idx.p == nullptr;
+    if (is_identity) *is_identity = ident ? 1 : 0;
+    if (e_idx2idx && !ident && g->E > 0)
+        GMX_HIP(hipMemcpy(e_idx2idx, g->e_idx2idx.p, sizeof(int32_t) * (size_t) g->E, hipMemcpyDeviceToHost));
+    return GMX_OK;
+}
+
 extern "C" int gmx_graph_free(gmx_graph_t* g) {
     if (g) {
         for (gmx_pr*& p : g->pr_cache) {

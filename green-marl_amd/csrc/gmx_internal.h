@@ -74,6 +74,9 @@ struct gmx_graph {
     bool has_reverse = false;
     // original numbering, rows ascending (semi-sorted)
     dbuf<int32_t> begin, node_idx, r_begin, r_node_idx;
+    // gm_graph's e_idx2idx (gm_graph.h:141, do_semi_sort gm_graph.cc:468-503): slot of the uploaded (unsorted) forward
+    // CSR that every slot of the sorted rows came from.  Empty: the upload was already in order (identity).
+    dbuf<int32_t> e_idx2idx;
     int device = 0;
     // PageRank plans built by the whole-kernel entries (fp32, fp64), kept for the next call on the same
     // graph: the plan is graph preprocessing, like the reverse CSR.  Freed with the graph.
@@ -91,7 +94,7 @@ struct gmx_graph {
 // keys are (row << 32 | col).  Sorts keys in place (double buffer), then writes
 // begin[V+1] and idx[E].
 int gmx_csr_from_keys(uint64_t* keys, uint64_t* keys_alt, int64_t V, int64_t E,
-                      int32_t* begin, int32_t* idx, hipStream_t stream);
+                      int32_t* begin, int32_t* idx, hipStream_t stream, int32_t* slots = nullptr);   // slots: [E] key order -> input position
 // keys[e] = (row(e) << 32 | col(e)) from a CSR; if transpose, (col << 32 | row).
 // perm (optional): map both endpoints through perm[] first.
 int gmx_keys_from_csr(const int32_t* begin, const int32_t* idx, int64_t V, int64_t E,

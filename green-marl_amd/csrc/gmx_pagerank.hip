@@ -404,6 +404,14 @@ __device__ __forceinline__ int pr_xcc_id() {
 #define PRW_ROWU ((PRW_ITEMS + 1 + 63) / 64)
 
 #define PRW_PAD(j) ((j) + ((j) >> 5))   // one pad word per 32: stride-8 lane accesses hit 32 different banks
+// Debug build (make debug: -DGMX_PR_BOUNDS): every index the wave workers derive from the block table is checked
+// against what the block may touch, a violation traps -- the launch dies at the faulty access instead of reading a
+// neighbour's page (tests/test_gpu_parity.py::test_pagerank_small_shapes_with_bounds_checks).
+#ifdef GMX_PR_BOUNDS
+#define PRW_CHECK(cond) do { if (!(cond)) __builtin_trap(); } while (0)
+#else
+#define PRW_CHECK(cond) do { } while (0)
+#endif
 template <typename S>
 struct prw_lds {
     S val[PRW_ITEMS + PRW_ITEMS / 32 + 2];
@@ -499,6 +507,8 @@ __device__ __forceinline__ void prw_issue(const S* __restrict__ s_hot, const prw
                                           const int32_t (&ix)[PRW_PER], const OUT& out, prw_regs<S>& g) {
     const int lane = threadIdx.x & 63;
     const int r0 = b0.r, nr = b1.r - b0.r + 1;
+    // a block is PRW_ITEMS consecutive items of the merge path: row ends [b0.r, b1.r) and edges [b0.e, b1.e)
+    PRW_CHECK(b0.r >= 0 && b1.r >= b0.r && b1.e >= b0.e && (b1.r - b0.r) + (b1.e - b0.e) <= PRW_ITEMS);
 #pragma unroll
     for (int u = 0; u < PRW_ROWU; u++) {
         const int i = lane + 64 * u;
@@ -540,6 +550,8 @@ __device__ __forceinline__ void prw_consume(prw_lds<S>* __restrict__ w, int64_t 
     const int nr = r1 - r0 + 1;
     const int nends = nr - 1;          // row-end items of this block
     const int total = nends + ne;      // path items of this block
+    PRW_CHECK(k >= 0 && ne >= 0 && ne <= PRW_ITEMS && nr >= 1 && nr <= PRW_ITEMS + 1 && total <= PRW_ITEMS);
+    PRW_CHECK(r1 <= rows);             // rb[r1] is the last row start a block reads: rb has rows + 1 entries
 #pragma unroll
     for (int u = 0; u < PRW_ROWU; u++) {
         const int i = lane + 64 * u;
@@ -548,7 +560,10 @@ __device__ __forceinline__ void prw_consume(prw_lds<S>* __restrict__ w, int64_t 
 #pragma unroll
     for (int u = 0; u < PRW_PER; u++) {
         const int j = lane + 64 * u;
-        if (j < ne) w->val[PRW_PAD(j)] = g.vv[u];
+        if (j < ne) {
+            PRW_CHECK(PRW_PAD(j) < (int) (sizeof(w->val) / sizeof(w->val[0])));
+            w->val[PRW_PAD(j)] = g.vv[u];
+        }
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible to all its lanes
@@ -563,10 +578,12 @@ __device__ __forceinline__ void prw_consume(prw_lds<S>* __restrict__ w, int64_t 
         int lo = d0 > ne ? d0 - ne : 0, hi = d0 < nends ? d0 : nends;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
+            PRW_CHECK(mid + 1 < nr);
             if (w->rb[mid + 1] - e0 <= d0 - mid - 1) lo = mid + 1; else hi = mid;
         }
         i = lo;
         j = d0 - lo;
+        PRW_CHECK(i >= 0 && i <= nends && j >= 0 && j <= ne);
     }
     double acc = 0.0, head = 0.0;
     int first_end = -1;
@@ -576,6 +593,7 @@ __device__ __forceinline__ void prw_consume(prw_lds<S>* __restrict__ w, int64_t 
     for (int sidx = 0; sidx < PRW_PER; sidx++) {
         if (active && d0 + sidx < total) {
             if (j < cur_end) {
+                PRW_CHECK(j < ne);
                 acc += (double) w->val[PRW_PAD(j)];
                 j++;
             } else {                                    // row i ends here

@@ -56,6 +56,13 @@ static constexpr int prc_tile_elems(int elem) { return (PRC_LDS_LIMIT - 16 * (PR
 #define PRC_Q1E 64
 #define PRC_Q2 128
 
+// debug build (make debug): indices derived from the plan's tables are checked, a violation traps
+#ifdef GMX_PR_BOUNDS
+#define PRC_CHECK(cond) do { if (!(cond)) __builtin_trap(); } while (0)
+#else
+#define PRC_CHECK(cond) do { } while (0)
+#endif
+
 struct prc_item1 { int32_t tile, g0, g1, form; };         // phase 1: groups [g0, g1) of the tile-major stream; form 1 = pair, 0 = edge
 struct prc_item2 { int32_t bin, g0, g1, slot; };          // phase 2: groups [g0, g1) of the bin-major stream; slot < 0: sole chunk
 struct prc_item3 { int32_t bin, slot0, nslots, pad; };    // phase 3: a split bin
@@ -414,6 +421,7 @@ __device__ __forceinline__ void prc_pair_block(const S* __restrict__ s_tile, S* 
             os[u] = ord;
             int at = (ord & m[u]) | (dummy & ~m[u]);
             if (NPASS > 1) at = (unsigned) at < (unsigned) CAP ? at : dummy;
+            PRC_CHECK(at >= 0 && at < CAP + 64);
             stage[at] = xs[u];
             ord -= m[u];
             acc = prc_clear_if(acc, m[u]);
@@ -428,6 +436,7 @@ __device__ __forceinline__ void prc_pair_block(const S* __restrict__ s_tile, S* 
             for (int r = 0; r < ROUNDS; r++) {
                 const int i = lane + 64 * r;
                 const unsigned at = i < p1 ? (unsigned) (shift0 + p0 + i) : sink;
+                PRC_CHECK(at <= sink);   // item slots lie below the sink slots
                 val[at] = stage[i];
             }
         } else {
@@ -435,6 +444,7 @@ __device__ __forceinline__ void prc_pair_block(const S* __restrict__ s_tile, S* 
 #pragma unroll
             for (int u = p * ROUNDS; u < (p + 1) * ROUNDS; u++) {
                 const unsigned at = m[u] ? (unsigned) (shift + p0 + os[u]) : sink;
+                PRC_CHECK(at <= sink);
                 val[at] = xs[u];
             }
         }
@@ -673,6 +683,7 @@ pr_cold_accum_kernel(const prc_item2* __restrict__ items, int n_items, unsigned 
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (r[j] == PRC_PAD) continue;
+                    PRC_CHECK(r[j] < (unsigned) BINROWS && x[j] >= 0.0 && x[j] <= 1.0);
                     const unsigned long long hi = prc_fix_hi(x[j]);
                     __hip_atomic_fetch_add(&s_acc[r[j]], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (LIMBS > 1) {

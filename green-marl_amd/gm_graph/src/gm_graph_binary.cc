@@ -86,13 +86,15 @@ bool gm_graph::load_binary(char* filename) {
     }
     load_mark("read + byte swap", tmark);
     // Post-load preparation (the reference: per-row std::sort + atomic scatter, both on the host,
-    // gm_graph_binary_loader.cc:191-197).  Rows are sorted on the host (parallel, rows already in order are
-    // skipped); with a GPU present the reverse CSR is built on the device (transposed 64-bit key radix sort,
-    // SURVEY.md section 8f rank 1) and copied back, the device copy staying as the mirror the kernels use.
+    // gm_graph_binary_loader.cc:191-197).  With a GPU present both happen on the device (SURVEY.md section 8f
+    // rank 1): do_semi_sort as a 64-bit (row, column) key radix sort that carries the slot numbers (e_idx2idx; a
+    // file whose rows are already in order -- anything store_binary wrote after a semi-sort -- is recognised by one
+    // pass over the keys and keeps the identity map), make_reverse_edges as the same sort over the transposed keys;
+    // the device copy stays as the mirror the kernels use.  Without a device: the host versions.
+    int ndev = 0;
+    if (_numEdges > 0 && e_idx2id == NULL && gmx_device_count(&ndev) == GMX_OK && ndev > 0 && build_reverse_on_device()) return true;
     do_semi_sort();
     load_mark("do_semi_sort (host)", tmark);
-    int ndev = 0;
-    if (_numEdges > 0 && gmx_device_count(&ndev) == GMX_OK && ndev > 0 && build_reverse_on_device()) return true;
     make_reverse_edges();
     return true;
 }
@@ -100,13 +102,33 @@ bool gm_graph::load_binary(char* filename) {
 bool gm_graph::build_reverse_on_device() {
     gmx_graph_t* dev = NULL;
     double tmark = load_now_ms();
-    if (gmx_graph_upload(begin, node_idx, NULL, NULL, _numNodes, _numEdges, 0, &dev) != GMX_OK) {
+    const uint32_t flags = _semi_sorted ? 0u : GMX_GRAPH_SORT_ROWS;
+    if (gmx_graph_upload(begin, node_idx, NULL, NULL, _numNodes, _numEdges, flags, &dev) != GMX_OK) {
         fprintf(stderr, "load_binary: device preparation failed (%s), using the host path\n", gmx_last_error());
         return false;
     }
-    load_mark("upload + device reverse CSR", tmark);
+    load_mark("upload + device row sort + reverse CSR", tmark);
     const node_t N = _numNodes;
     const edge_t M = _numEdges;
+    if (!_semi_sorted) {   // do_semi_sort (gm_graph.cc:468-503): sorted rows and the map to the slots of the file
+        int ident = 1;
+        edge_t* map = new edge_t[(size_t) M];
+        bool ok = gmx_graph_edge_order(dev, map, &ident) == GMX_OK;
+        if (ok && ident) {
+#pragma omp parallel for
+            for (edge_t e = 0; e < M; e++) map[e] = e;
+        } else if (ok) ok = gmx_graph_download(dev, NULL, node_idx, NULL, NULL) == GMX_OK;
+        if (!ok) {
+            fprintf(stderr, "load_binary: device row sort failed (%s), using the host path\n", gmx_last_error());
+            delete[] map;
+            gmx_graph_free(dev);
+            return false;
+        }
+        delete[] e_idx2idx;
+        e_idx2idx = map;
+        _semi_sorted = true;
+        load_mark(ident ? "rows already in order: identity e_idx2idx" : "download sorted rows + e_idx2idx", tmark);
+    }
     r_begin = new edge_t[(size_t) N + 1];
     r_node_idx = new node_t[(size_t) M];
     e_rev2idx = new edge_t[(size_t) M];

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgmx.so")
+LIB_PATH = os.environ.get("GMX_LIB") or os.path.join(_HERE, "libgmx.so")   # GMX_LIB: the debug build of a test
 
 GMX_GRAPH_SORT_ROWS = 0x1
 GMX_GRAPH_NO_REVERSE = 0x2
@@ -43,7 +43,7 @@ class DeviceInfo(C.Structure):
 EXPORTS = [
     "gmx_last_error", "gmx_device_count", "gmx_set_device", "gmx_device_info", "gmx_copy_bandwidth",
     "gmx_graph_upload", "gmx_graph_from_edges", "gmx_graph_create_rmat", "gmx_graph_free", "gmx_graph_symmetrize",
-    "gmx_graph_num_nodes", "gmx_graph_num_edges", "gmx_graph_download",
+    "gmx_graph_num_nodes", "gmx_graph_num_edges", "gmx_graph_download", "gmx_graph_edge_order",
     "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_sssp", "gmx_avg_teen_cnt", "gmx_conduct", "gmx_triangle_counting", "gmx_triangle_counting_part", "gmx_graph_reverse_edge_map",
     "gmx_bfs_create", "gmx_bfs_free", "gmx_bfs_start", "gmx_bfs_step_begin", "gmx_bfs_found_bitmap", "gmx_bfs_step_end",
     "gmx_bfs_download",
@@ -90,6 +90,7 @@ def lib():
         L.gmx_graph_num_edges.argtypes = [vp]
         L.gmx_graph_num_edges.restype = i64
         L.gmx_graph_download.argtypes = [vp, vp, vp, vp, vp]
+        L.gmx_graph_edge_order.argtypes = [vp, vp, C.POINTER(C.c_int)]
         L.gmx_pagerank_f64.argtypes = [vp, C.c_double, C.c_double, i32, vp, C.POINTER(Stats)]
         L.gmx_pagerank_f32.argtypes = [vp, C.c_float, C.c_float, i32, vp, C.POINTER(Stats)]
         L.gmx_hop_dist.argtypes = [vp, i32, vp, C.POINTER(Stats)]
@@ -302,6 +303,14 @@ class Graph:
         res, st = C.c_float(0), Stats()
         _ck(lib().gmx_conduct(self._h, member.ctypes.data if self.V else None, int(num), C.byref(res), C.byref(st)))
         return np.float32(res.value), st.as_dict()
+
+    def edge_order(self):
+        """e_idx2idx after an upload with GMX_GRAPH_SORT_ROWS: uploaded slot of every slot of the sorted rows;
+        None when the upload was already in order (identity)."""
+        out = np.zeros(max(self.E, 1), np.int32)[:self.E].copy()
+        ident = C.c_int(1)
+        _ck(lib().gmx_graph_edge_order(self._h, out.ctypes.data if self.E else None, C.byref(ident)))
+        return None if ident.value else out
 
     def reverse_edge_map(self):
         """e_rev2idx: forward slot mirrored by each reverse-CSR slot."""

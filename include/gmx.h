@@ -94,6 +94,11 @@ int gmx_graph_symmetrize(const gmx_graph_t* g, gmx_graph_t** out);
 int gmx_graph_free(gmx_graph_t* g);
 int64_t gmx_graph_num_nodes(const gmx_graph_t* g);
 int64_t gmx_graph_num_edges(const gmx_graph_t* g);
+/* gm_graph's e_idx2idx[E] (gm_graph.h:141, do_semi_sort gm_graph.cc:468-503) after an upload with
+ * GMX_GRAPH_SORT_ROWS: for every slot of the sorted rows, the slot of the uploaded CSR it came from (equal
+ * destinations keep their order).  *is_identity = 1 when the upload was already in order; e_idx2idx is then not
+ * written.  Edge properties passed later (gmx_sssp's len) are indexed by the UPLOADED slots. */
+int gmx_graph_edge_order(const gmx_graph_t* g, gmx_edge_t* e_idx2idx, int* is_identity);
 /* gm_graph's e_rev2idx[E] (gm_graph.h:141-142): forward slot mirrored by each slot of the reverse CSR. */
 int gmx_graph_reverse_edge_map(const gmx_graph_t* g, gmx_edge_t* e_rev2idx);
 /* Copy the device CSR back (any pointer may be NULL).  Lets a host gm_graph be

@@ -50,6 +50,7 @@ def ref_lib():
     R.ref_rmat_csr.argtypes = [C.c_int32, C.c_int32, C.c_long, C.c_double, C.c_double, C.c_double, C.c_int, i32p, i32p]
     R.ref_prepare.argtypes = [C.c_int32, C.c_int32, i32p, i32p, i32p, i32p, i32p]
     R.ref_store_binary.argtypes = [C.c_char_p, C.c_int32, C.c_int32, i32p, i32p]
+    R.ref_load_adj.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), i32p, i32p, C.c_int32, C.c_int32]
     R.ref_load_binary.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     R.ref_pagerank.argtypes = [C.c_int32, C.c_int32, i32p, i32p, C.c_double, C.c_double, C.c_int32, f64p,
@@ -285,6 +286,17 @@ def main():
     hand["star64"] = (64, [(0, i) for i in range(1, 64)] + [(i, 0) for i in range(1, 64)], 0)
     k6 = [(i, j) for i in range(6) for j in range(6) if i != j]
     hand["k6"] = (6, k6, 2)
+    # the reference's own sample adjacency lists, read by ITS loader (sparse keys renumbered, rows semi-sorted)
+    for nm, rel in (("adj_very_small_sample", "apps/output_cpp/gm_graph/test/very_small_sample.adj"),
+                    ("adj_cpp_be_test", "test/cpp_be/test.adj")):
+        N_, M_ = C.c_int32(0), C.c_int32(0)
+        ab, an = np.zeros(4097, np.int32), np.zeros(65536, np.int32)
+        rc = R.ref_load_adj(os.path.join("/root/reference", rel).encode(), C.byref(N_), C.byref(M_), ab,
+                            an, 4096, 65536)
+        assert rc == 0, (nm, rc)
+        ab, an = ab[:N_.value + 1], an[:M_.value]
+        hand[nm] = (N_.value, [(int(v), int(an[e])) for v in range(N_.value) for e in range(ab[v], ab[v + 1])], 0)
+        print("%s: %d vertices, %d edges from the reference's adjacency loader" % (nm, N_.value, M_.value))
     for name, (N, edges, root) in hand.items():
         src = np.array([e[0] for e in edges], np.int32)
         dst = np.array([e[1] for e in edges], np.int32)

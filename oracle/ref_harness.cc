@@ -87,6 +87,25 @@ int ref_load_binary(const char* path, int32_t* N, int32_t* M,
     return 0;
 }
 
+/* The reference's adjacency-list loader (gm_graph_adj_loader.cc:112-219: sparse vertex keys are renumbered in order
+ * of appearance, destination-only vertices appended, rows semi-sorted, reverse edges built), one double vertex
+ * value and one double edge value per entry -- the layout of its own sample files
+ * (apps/output_cpp/gm_graph/test/very_small_sample.adj, test/cpp_be/test.adj). */
+int ref_load_adj(const char* path, int32_t* N, int32_t* M, int32_t* begin, int32_t* node_idx, int32_t cap_n, int32_t cap_m) {
+    gm_graph g;
+    std::vector<VALUE_TYPE> vs, es;
+    vs.push_back(GMTYPE_DOUBLE);
+    es.push_back(GMTYPE_DOUBLE);
+    std::vector<void*> vp, ep;
+    if (!g.load_adjacency_list(path, vs, es, vp, ep, " \t", false)) return -1;
+    *N = g.num_nodes();
+    *M = g.num_edges();
+    if (*N > cap_n || *M > cap_m) return -2;
+    memcpy(begin, g.begin, sizeof(int32_t) * ((size_t) *N + 1));
+    memcpy(node_idx, g.node_idx, sizeof(int32_t) * (size_t) *M);
+    return 0;
+}
+
 /* ---- pagerank: plain emission against the reference runtime ---- */
 int ref_pagerank(int32_t N_, int32_t M, const int32_t* begin, const int32_t* node_idx,
                  double e, double d, int32_t max, double* G_pg_rank, int nthreads, int32_t* iters) {

@@ -51,9 +51,114 @@ def test_pagerank_full_size_sampled_rows(gmx, scale, elem, tol):
         src = rn[rb[t]:rb[t + 1]]
         want = (1 - d) / N + d * np.sum(prev[src] / outdeg[src])
         worst = max(worst, abs(cur[t] - want) / want)
-    # prev itself is rounded to the storage type, so one extra ulp of slack for fp32
-    assert worst < 2 * tol, worst
+    # the host recomputation divides the (storage-rounded) ranks of iteration k in fp64 where the device gathers the
+    # storage-rounded quotients: <= one storage ulp per term (6e-8 for fp32), well inside the bar itself
+    assert worst < tol, worst
     g.free()
+
+
+@pytest.mark.parametrize("scale,elem,tol", [(24, 4, 1e-6), (24, 8, 1e-12)])
+def test_pagerank_rmat24_converged_against_oracle(gmx, scale, elem, tol):
+    """BASELINE configs[1] end to end: RMAT-24, the driver's parameters (e = 0.001, d = 0.85, max = 100,
+    pagerank_main.cc:11-16), the whole-kernel entry (gmx_pagerank_f32 / _f64), EVERY rank against the fp64 oracle
+    (the OpenMP restatement of the emitted loop on this box's host cores), same iteration count."""
+    import pyoracle as po
+    N, M = 1 << scale, 16 << scale
+    g = gmx.Graph.rmat(N, M, 1997, 0.57, 0.19, 0.19, True)
+    begin, node_idx, rb, rn = g.download()
+    og = po.Graph(N, begin, node_idx, rb, rn)
+    want, it, want_diff = po.pagerank(og, 0.001, 0.85, 100)
+    rank, st = g.pagerank(0.001, 0.85, 100, np.float32 if elem == 4 else np.float64)
+    assert st["iterations"] == it, (st, it)
+    err = np.abs(rank.astype(np.float64) - want) / want
+    assert float(err.max()) < tol, (float(err.max()), int(err.argmax()))
+    assert abs(st["last_diff"] - want_diff) <= (1e-3 if elem == 4 else 1e-9) * want_diff
+    g.free()
+
+
+def test_pagerank_livejournal_sized_standin_through_driver(gmx, tmp_path):
+    """BASELINE configs[0] names soc-LiveJournal1 (4,847,571 vertices, 68,993,774 edges), which is not in the
+    container and cannot be fetched.  Stand-in, stated as such: a seeded random graph of EXACTLY that size with a
+    skewed degree sequence, written as a reference-format .bin, run through the emitted driver (bin/pagerank,
+    default parameters) and compared with the oracle on the same file: the printed rank[0..3] to the driver's 9
+    decimals, and the whole array through the C ABI at 1e-12."""
+    import os
+    import re
+    import subprocess
+
+    import pyoracle as po
+    from conftest import ROOT
+    V, E = 4847571, 68993774
+    rng = np.random.default_rng(20261004)
+    src = (V * rng.random(E) ** 3).astype(np.int32)          # a few heavy sources, a long light tail
+    dst = (V * rng.random(E) ** 2).astype(np.int32)
+    g = gmx.Graph.from_edges(V, src, dst)
+    del src, dst
+    begin, node_idx, rb, rn = g.download()
+    og = po.Graph(V, begin, node_idx, rb, rn)
+    path = str(tmp_path / "lj_sized.bin")
+    po.store_binary(path, og)
+    want, it, _ = po.pagerank(og, 0.001, 0.85, 100)
+    rank, st = g.pagerank(0.001, 0.85, 100, np.float64)
+    assert st["iterations"] == it
+    assert float(np.max(np.abs(rank - want) / want)) < 1e-12
+    g.free()
+    exe = os.path.join(ROOT, "green-marl_amd", "bin", "pagerank")
+    r = subprocess.run([exe, path, "8", "/dev/null"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "N = %d, M = %d" % (V, E) in r.stdout
+    got = [x for x in re.findall(r"rank\[\d\] = ([0-9.]+)", r.stdout)]
+    assert got == ["%0.9f" % x for x in want[:4]], (got, want[:4])
+
+
+KAT_RANK = {"soc-LiveJournal1.bin": [0.000001174, 0.000004149, 0.000002173, 0.000001640],
+            "twitter_rv.bin": [0.000000065, 0.000000021, 0.000000014, 0.000000031],
+            "huge.bin": [0.000000002, 0.000000006, 0.000000006, 0.000000003],
+            "big.bin": [0.000000098, 0.000000043, 0.000000039, 0.000000155],
+            "test.bin": [0.000000928, 0.000001235, 0.000000838, 0.000000673]}
+KAT_DIST = {"soc-LiveJournal1.bin": [0, 1, 1, 1, 1, 1, 1, 1, 1, 1], "twitter_rv.bin": [0, 1, 1, 1, 1, 1, 1, 1, 1, 1]}
+KAT_TC = {"soc-LiveJournal1.bin": 132775101, "tiny.bin": 179}
+
+
+def _dataset(name):
+    import os
+    for d in [os.environ.get("GMX_DATASETS", ""), "/data", "/datasets", os.path.expanduser("~/datasets"),
+              os.path.expanduser("~/projects/gm-graphs")]:
+        if d and os.path.exists(os.path.join(d, name)):
+            return os.path.join(d, name)
+    return None
+
+
+@pytest.mark.parametrize("name", sorted(set(KAT_RANK) | set(KAT_DIST) | set(KAT_TC)))
+def test_reference_dataset_kats(gmx, name):
+    """The reference's own known-answer values (scripts/extract_result.py:37-75 hop_dist dist[0..9], :212-215
+    triangle counts, :219-250 PageRank rank[0..3] to 9 decimals), checked through the emitted drivers whenever the
+    named .bin file exists on the box (GMX_DATASETS or a few usual places).  None of the datasets ships with the
+    reference and there is no network: without the file the case is skipped -- parity against these KATs is unpinned."""
+    import os
+    import re
+    import subprocess
+
+    from conftest import ROOT
+    path = _dataset(name)
+    if path is None:
+        pytest.skip("%s not on this box" % name)
+    bins = os.path.join(ROOT, "green-marl_amd", "bin")
+
+    def run(app):
+        r = subprocess.run([os.path.join(bins, app), path, "8", "/dev/null"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, timeout=1100)
+        assert r.returncode == 0, r.stdout[-2000:]
+        return r.stdout
+    if name in KAT_RANK:
+        got = [float(x) for x in re.findall(r"rank\[\d\] = ([0-9.]+)", run("pagerank"))]
+        assert got == KAT_RANK[name], (got, KAT_RANK[name])
+    if name in KAT_DIST:
+        got = [int(x) for x in re.findall(r"dist\[\d\] = (-?\d+)", run("hop_dist"))]
+        assert got == KAT_DIST[name]
+    if name in KAT_TC:
+        m = re.search(r"number of triangles: (\d+)", run("triangle_counting"))
+        assert m and int(m.group(1)) == KAT_TC[name]
 
 
 @pytest.mark.parametrize("scale,permute", [(24, False), (26, False), (26, True)])

@@ -287,6 +287,66 @@ def test_pagerank_row_chunked_steps(gmx, scale, nranks, chunks, elem):
     g.free()
 
 
+SMALL_SHAPES_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path[:0] = [os.path.join(ROOT, "green-marl_amd"), os.path.join(ROOT, "oracle")]
+import gmx
+import pyoracle as po
+gmx.require_device()
+assert gmx.LIB_PATH.endswith("libgmx_dbg.so")
+def check(og, tag):
+    want, it, _ = po.pagerank(og, 0.001, 0.85, 100)
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    for dt, tol in ((np.float64, 1e-12), (np.float32, 1e-6)):
+        rank, st = g.pagerank(0.001, 0.85, 100, dt)                     # whole-kernel entry, default options
+        assert st["iterations"] == it and np.max(np.abs(rank - want) / want) < tol, (tag, dt, st)
+    want8 = po.pagerank(og, 1e-300, 0.85, 8)[0]
+    for opts in (1, 3, 7, 15):                                          # plain, LDS tile, sliced pull, binned
+        for elem in (8, 4):
+            if opts == 15:
+                os.environ["GMX_PR_COLD"] = "0"
+            st = gmx.PageRankState(g, elem, 0, 1, opts)
+            st.reset(0.85)
+            for _ in range(8):
+                st.step()
+            err = np.max(np.abs(st.download() - want8) / want8)
+            assert err < (1e-12 if elem == 8 else 1e-6), (tag, opts, elem, err)
+            st.free()
+    g.free()
+# the shape of the round-1 fault: RMAT-12 without the final permutation, fp64, whole-kernel entry
+check(po.rmat_graph(12, permute=False), "rmat12")
+# one merge-path block in all (rows + edges <= 512)
+src = np.arange(100, dtype=np.int32); dst = (src * 7 + 3) % 100
+check(po.graph_from_edges(100, np.concatenate([src, src]), np.concatenate([dst.astype(np.int32), ((dst + 1) % 100).astype(np.int32)])), "one_block")
+# the last block ends exactly on the last row end: rows + edges a multiple of 512
+n = 128; e = 3 * 512 - n
+rng = np.random.default_rng(3)
+s2 = rng.integers(0, n, e).astype(np.int32); d2 = np.concatenate([rng.integers(0, n - 1, e - 1), [n - 1]]).astype(np.int32)
+check(po.graph_from_edges(n, s2, d2), "block_ends_on_last_row")
+check(po.rmat_graph(15, permute=True), "rmat15")
+print("BOUNDS OK")
+"""
+
+
+def test_pagerank_small_shapes_with_bounds_checks(gmx, tmp_path):
+    """Round 1 had one `Memory access fault by GPU` in `bin/gmx_bench` (RMAT-12, gmx_pagerank_f64, the unsliced
+    wave-worker kernel) while those kernels were being written; it did not come back and its cause was not
+    recorded.  This runs exactly that shape -- plus a graph that is a single merge-path block, one whose
+    last block ends on the last row, and every kernel variant -- on a build whose wave workers check each index
+    they derive from the block table (make debug: -DGMX_PR_BOUNDS, a violation traps and kills the process)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    pkg = os.path.join(ROOT, "green-marl_amd")
+    subprocess.check_call(["make", "-C", pkg, "-j8", "debug"], stdout=subprocess.DEVNULL)
+    script = tmp_path / "small_shapes.py"
+    script.write_text("ROOT = %r\n" % ROOT + SMALL_SHAPES_SCRIPT)
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, GMX_LIB=os.path.join(pkg, "libgmx_dbg.so")),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and "BOUNDS OK" in r.stdout, r.stdout[-3000:]
+
+
 @pytest.mark.parametrize("scale,nranks,chunks,elem,hot,chunk2", [
     (18, 1, 1, 4, 16384, 0), (18, 1, 1, 8, 16384, 0), (18, 1, 2, 4, 32768, 8), (18, 1, 1, 8, 16384, 16),
     (18, 4, 1, 8, 16384, 0), (19, 2, 3, 4, 49152, 64), (18, 3, 2, 8, 16384, 8), (17, 1, 1, 4, 16384, 8),
@@ -531,6 +591,43 @@ def test_sssp_golden_and_oracle(gmx, golden):
     length[(srcs == 0) & (og.node_idx == n // 2)] = 900          # 0 -> n/2 directly costs 900, via the chain 1000
     g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
     assert np.array_equal(g.sssp(length, 0)[0], po.sssp(og, length, 0)[0])
+    g.free()
+
+
+def test_sssp_edge_property_follows_device_row_sort(gmx):
+    """A host graph that is frozen but not semi-sorted (prepare_external_creation with caller-filled rows, e.g.
+    create_uniform_random_graph_new, graph_gen.cc:12-105) is uploaded with GMX_GRAPH_SORT_ROWS: the device sorts
+    the rows.  The edge property of sssp stays indexed by the CALLER's slots (the reference's sssp never sorts and
+    walks the rows as stored), so the library has to carry it through the sort (e_idx2idx, gm_graph.cc:468-503)."""
+    rng = np.random.default_rng(5)
+    N, M = 3000, 40000
+    src = rng.integers(0, N, M).astype(np.int32)
+    dst = rng.integers(0, N, M).astype(np.int32)
+    order = np.argsort(src, kind="stable")                # rows in arrival order: destinations unsorted, duplicates kept
+    src, dst = src[order], dst[order]
+    begin = np.zeros(N + 1, np.int32)
+    np.cumsum(np.bincount(src, minlength=N), out=begin[1:])
+    length = rng.integers(1, 50, M).astype(np.int32)
+    og = po.Graph(N, begin, dst.copy())                   # the oracle walks the rows as stored
+    root = int(src[0])
+    want = po.sssp(og, length, root)[0]
+    g = gmx.Graph.upload(begin, dst, None, None, flags=gmx.GMX_GRAPH_SORT_ROWS)
+    b2, sorted_idx, _, _ = g.download()
+    emap = g.edge_order()
+    assert emap is not None and np.array_equal(b2, begin)
+    assert np.array_equal(sorted_idx, dst[emap])           # e_idx2idx: sorted slot -> uploaded slot
+    assert np.array_equal(np.sort(emap), np.arange(M))
+    rows = np.repeat(np.arange(N), np.diff(begin))
+    assert np.all((np.diff(sorted_idx) >= 0) | (np.diff(rows) > 0))     # every row ascending
+    same = (np.diff(sorted_idx) == 0) & (np.diff(rows) == 0)
+    assert np.all(np.diff(emap)[same] > 0)                 # equal destinations keep their uploaded order
+    dist, _ = g.sssp(length, root)
+    assert np.array_equal(dist, want)
+    g.free()
+    # rows already in order: no map, same answers
+    g = gmx.Graph.upload(begin, sorted_idx, None, None, flags=gmx.GMX_GRAPH_SORT_ROWS)
+    assert g.edge_order() is None
+    assert np.array_equal(g.sssp(length[emap], root)[0], want)
     g.free()
 
 

@@ -144,6 +144,28 @@ def test_driver_rmat_input(host_built, golden):
     assert got == [float("%0.9f" % x) for x in m["rank_head"]]
 
 
+def _unsorted_check(tmp_path, gpu):
+    exe = str(tmp_path / "unsorted_check")
+    subprocess.check_call(["g++"] + CXX_FLAGS + [os.path.join(ROOT, "tests", "cpp", "unsorted_check.cc"), "-o", exe] + LINK)
+    r = subprocess.run([exe, str(tmp_path / "unsorted.bin")] + (["gpu"] if gpu else []), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout)
+    return r.stdout
+
+
+def test_load_binary_semi_sorts_unsorted_rows(host_built, tmp_path):
+    """load_binary of a file with unsorted rows: sorted rows + e_idx2idx + reverse CSR (host path on this box)."""
+    assert "load_binary of unsorted rows ok" in _unsorted_check(tmp_path, False)
+
+
+@pytest.mark.gpu
+def test_unsorted_host_graph_on_device(host_built, tmp_path):
+    """The same through the device row sort, and sssp through the generated entry on a host graph that is frozen
+    but not semi-sorted: the caller's len[] has to follow the device's row sort."""
+    out = _unsorted_check(tmp_path, True)
+    assert "load_binary of unsorted rows ok" in out and "sssp on an unsorted host graph ok" in out
+
+
 @pytest.mark.gpu
 def test_gm_graph_api_with_device(host_built, golden, tmp_path):
     """Same API check on a box with a GPU: load_binary then builds the reverse CSR on the device."""
