@@ -639,6 +639,10 @@ extern "C" int gmx_graph_free(gmx_graph_t* g) {
             if (p) gmx_pr_free(p);
             p = nullptr;
         }
+        for (gmx_pr_multi*& m : g->pr_multi_cache) {
+            if (m) gmx_pr_multi_free(m);
+            m = nullptr;
+        }
         delete g->tc_oriented;
         g->tc_oriented = nullptr;
         if (g->bfs_cache) gmx_bfs_free(g->bfs_cache);

@@ -81,6 +81,8 @@ struct gmx_graph {
     // PageRank plans built by the whole-kernel entries (fp32, fp64), kept for the next call on the same
     // graph: the plan is graph preprocessing, like the reverse CSR.  Freed with the graph.
     gmx_pr* pr_cache[2] = {nullptr, nullptr};
+    // the same for the multi-GPU form of those entries (gmx_pr_multi.hip): N rank states driven by one host thread
+    struct gmx_pr_multi* pr_multi_cache[2] = {nullptr, nullptr};
     // triangle counting: -1 not examined, 0 general graph, 1 symmetric and simple -> `tc_oriented` holds the
     // forward CSR of the same graph renumbered by ascending degree (its reverse CSR is the same arrays)
     int tc_sym_state = -1;
@@ -134,6 +136,13 @@ bool pr_cold_covers_all_rows(const pr_cold* c);
 const void* pr_cold_partial(const pr_cold* c);   // [nactive] x elem, indexed like the per-slice partial sums
 int64_t pr_cold_edges(const pr_cold* c);
 int64_t pr_cold_items(const pr_cold* c);
+
+// ---- whole-kernel PageRank over several GPUs from one host thread (gmx_pr_multi.hip) ----
+struct gmx_pr_multi;
+int gmx_pr_multi_ranks(const gmx_graph* g);    // ranks the entry uses for this graph (GMX_DEVICES, GMX_PR_RANKS); 1 = single GPU
+int gmx_pr_multi_create(gmx_graph* g, int elem, int nranks, gmx_pr_multi** out);
+int gmx_pr_multi_run(gmx_pr_multi* m, double e, double d, int32_t max_iter, void* rank_host, gmx_stats_t* stats);
+void gmx_pr_multi_free(gmx_pr_multi* m);
 
 static inline int gmx_bits_for(int64_t v) {  // bits needed to represent values in [0, v)
     int b = 1;

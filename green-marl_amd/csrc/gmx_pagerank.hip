@@ -1958,6 +1958,15 @@ static int pagerank_entry(gmx_graph_t* g, double e, double d, int32_t max_iter, 
     GMX_REQUIRE(g && rank_host, "NULL argument");
     if (stats) memset(stats, 0, sizeof(*stats));
     if (g->V == 0) return GMX_OK;
+    // several GPUs (or GMX_PR_RANKS > 1): one host thread drives N rank states (gmx_pr_multi.hip); the plan is cached
+    // on the graph like the single-GPU one
+    const int nranks = gmx_pr_multi_ranks(g);
+    const char* ex = getenv("GMX_EXCHANGE");
+    if (nranks > 1 || (ex && *ex && strcmp(ex, "peer") != 0)) {   // (an RCCL exchange can be asked for with one rank too)
+        gmx_pr_multi*& mc = g->pr_multi_cache[sizeof(S) == 4 ? 0 : 1];
+        if (mc == nullptr) GMX_CHECK(gmx_pr_multi_create(g, (int) sizeof(S), nranks, &mc));
+        return gmx_pr_multi_run(mc, e, d, max_iter, (void*) rank_host, stats);
+    }
     gmx_pr_t*& cached = g->pr_cache[sizeof(S) == 4 ? 0 : 1];
     if (cached == nullptr) GMX_CHECK(gmx_pr_create(g, (int) sizeof(S), 0, 1, gmx_pr_default_options(g->V, 1), &cached));
     gmx_pr_t* p = cached;

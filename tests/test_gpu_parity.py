@@ -287,6 +287,31 @@ def test_pagerank_row_chunked_steps(gmx, scale, nranks, chunks, elem):
     g.free()
 
 
+@pytest.mark.parametrize("scale,ranks,exchange", [(15, 3, "peer"), (18, 2, "peer"), (21, 4, "peer"), (16, 1, "allgather"), (16, 1, "allreduce")])
+def test_pagerank_entry_drives_several_ranks_from_one_thread(gmx, scale, ranks, exchange, monkeypatch):
+    """gmx_pagerank_f64 / _f32 over N rank states from one host thread (gmx_pr_multi.hip: per-rank streams, peer
+    copies behind every sweep, events as the barrier, diff summed in rank order).  The box has one GPU, so the ranks
+    share it (GMX_PR_RANKS); the RCCL forms of the exchange need one rank per device and are run with a single rank
+    (library loading, communicator, group calls).  Results: the oracle's, iteration count included."""
+    og = po.rmat_graph(scale, permute=True) if scale <= 18 else None
+    if og is None:
+        g = gmx.Graph.rmat(1 << scale, 16 << scale, 1997, 0.57, 0.19, 0.19, True)
+        begin, node_idx, rb, rn = g.download()
+        og = po.Graph(1 << scale, begin, node_idx, rb, rn)
+    else:
+        g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    want, it, want_diff = po.pagerank(og, 0.001, 0.85, 100)
+    monkeypatch.setenv("GMX_PR_RANKS", str(ranks))
+    monkeypatch.setenv("GMX_EXCHANGE", exchange)
+    for dt, tol in ((np.float64, PR_RTOL_F64), (np.float32, PR_RTOL_F32)):
+        rank, st = g.pagerank(0.001, 0.85, 100, dt)
+        assert st["iterations"] == it, (dt, st, it)
+        assert rel_err(rank, want) < tol
+        rank2, st2 = g.pagerank(0.001, 0.85, 100, dt)          # the cached plan, and run-to-run identical
+        assert np.array_equal(rank, rank2) and st2["last_diff"] == st["last_diff"]
+    g.free()
+
+
 SMALL_SHAPES_SCRIPT = r"""
 import os, sys
 import numpy as np

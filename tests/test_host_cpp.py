@@ -167,6 +167,21 @@ def test_unsorted_host_graph_on_device(host_built, tmp_path):
 
 
 @pytest.mark.gpu
+def test_driver_pagerank_same_lines_for_any_rank_count(host_built):
+    """bin/pagerank (the emitted driver, unchanged) on one rank and on several rank states driven from the one
+    host thread prints the same rank[i] lines (9 decimals) and the same iteration behaviour."""
+    def lines(env):
+        r = subprocess.run([os.path.join(PKG, "bin", "pagerank"), "RMAT:20:1", "16", "/dev/null"], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, env=dict(os.environ, **env), timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:]
+        return re.findall(r"rank\[\d\] = [0-9.]+", r.stdout)
+    one = lines({"GMX_DEVICES": "1", "GMX_PR_RANKS": "1"})
+    assert len(one) == 4
+    assert lines({"GMX_PR_RANKS": "4"}) == one
+    assert lines({}) == one                      # every visible device, one rank each
+
+
+@pytest.mark.gpu
 def test_gm_graph_api_with_device(host_built, golden, tmp_path):
     """Same API check on a box with a GPU: load_binary then builds the reverse CSR on the device."""
     test_gm_graph_api(host_built, golden, tmp_path)
