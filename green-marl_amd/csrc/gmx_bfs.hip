@@ -694,6 +694,212 @@ extern "C" int gmx_sssp(gmx_graph_t* g, gmx_node_t root, const int32_t* len_host
     return GMX_OK;
 }
 
+// ------------------------------------------------------------------ BFS object: InBFS / InReverse
+// The device counterpart of gm_bfs_template<level_t = short, ..., save_child> (gm_bfs_template.h:14-312) as the
+// emitted `InBFS(v: G.Nodes From s) {..} InReverse {..}` uses it (gm_cpp_gen_bfs.cc:88-275):
+//   prepare(root) + do_bfs_forward()   the direction-optimising traversal above records every vertex's level; the
+//                                      vertices are then listed level by level (the template's level queues);
+//   visit_fw(v) for every v, level 0 first; do_bfs_reverse(): visit_rv(v), deepest level first (:272-312);
+//   v.UpNbrs   = slots of v's REVERSE row whose source lies one level up   (gm_cpp_gen_foreach.cc:173: the emitted
+//                `if (get_level(w) != (get_curr_level() - 1)) continue;`)
+//   v.DownNbrs = slots of v's forward row that are down edges; an edge v -> u is one iff level(u) == level(v) + 1
+//                (iterate_neighbor_* :581-682).  The device derives that from the levels instead of keeping the
+//                template's one byte per edge; where the template drops down edges (bottom-up levels record none,
+//                :400-403,689-708; several threads race on the child's level, :596-620) this is the definition
+//                those flags were meant to implement (tests/golden/manifest.json lists the fixtures where the compiled
+//                reference deviates from it).
+// A visit is a device callback: one thread per vertex of the level walks the row in slot order, so a float Sum adds
+// its terms in exactly the emitted order and the results are bit-identical to the single-threaded reference.
+struct bfs_order {
+    dbuf<uint32_t> key, key2;     // levels as sort keys (unreached: INT_MAX, last)
+    dbuf<int32_t> id, order;      // order[]: vertices by level
+    dbuf<int64_t> off;            // [levels + 1] first entry of every level in order[]
+    dbuf<char> tmp;
+    size_t tmp_bytes = 0;
+    std::vector<int64_t> h_off;
+    int32_t levels = 0;           // number of levels (deepest + 1)
+};
+
+__global__ void bfs_order_key_kernel(const int32_t* __restrict__ dist, int64_t V, uint32_t* __restrict__ key, int32_t* __restrict__ id) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < V; i += stride) {
+        key[i] = (uint32_t) dist[i];
+        id[i] = (int32_t) i;
+    }
+}
+__global__ void bfs_order_off_kernel(const uint32_t* __restrict__ key, int64_t V, int32_t levels, int64_t* __restrict__ off) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l > levels) return;
+    int64_t lo = 0, hi = V;   // first entry with level >= l
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (key[mid] < (uint32_t) l) lo = mid + 1; else hi = mid;
+    }
+    off[l] = lo;
+}
+
+// b has finished a traversal: list its vertices by level
+static int bfs_make_order(gmx_bfs* b, bfs_order* o) {
+    const int64_t V = b->V;
+    if (!o->key.p) {
+        GMX_CHECK(o->key.alloc((size_t) V));
+        GMX_CHECK(o->key2.alloc((size_t) V));
+        GMX_CHECK(o->id.alloc((size_t) V));
+        GMX_CHECK(o->order.alloc((size_t) V));
+        GMX_HIP(rocprim::radix_sort_pairs(nullptr, o->tmp_bytes, o->key.p, o->key2.p, o->id.p, o->order.p, (size_t) V, 0u, 32u, 0));
+        GMX_CHECK(o->tmp.alloc(o->tmp_bytes));
+    }
+    o->levels = b->level;   // levels completed by the traversal = deepest level + 1
+    hipLaunchKernelGGL(bfs_order_key_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, (const int32_t*) b->dist.p, V, o->key.p, o->id.p);
+    size_t tb = o->tmp_bytes;
+    GMX_HIP(rocprim::radix_sort_pairs((void*) o->tmp.p, tb, o->key.p, o->key2.p, o->id.p, o->order.p, (size_t) V, 0u, 32u, 0));
+    if (o->off.n < (size_t) o->levels + 2) GMX_CHECK(o->off.alloc((size_t) o->levels + 2));
+    hipLaunchKernelGGL(bfs_order_off_kernel, dim3((o->levels + 1 + 255) / 256), dim3(256), 0, 0, (const uint32_t*) o->key2.p, V, o->levels, o->off.p);
+    o->h_off.resize((size_t) o->levels + 1);
+    GMX_HIP(hipMemcpy(o->h_off.data(), o->off.p, sizeof(int64_t) * ((size_t) o->levels + 1), hipMemcpyDeviceToHost));
+    return GMX_OK;
+}
+
+// root's traversal -> b->dist; returns when it is complete
+static int bfs_run(gmx_bfs* b, gmx_node_t root) {
+    GMX_CHECK(gmx_bfs_start(b, root));
+    int64_t next = 0;
+    int need = 0;
+    do {
+        GMX_CHECK(gmx_bfs_step_begin(b, &need));
+        GMX_CHECK(gmx_bfs_step_end(b, &next));
+    } while (next > 0);
+    return GMX_OK;
+}
+
+// visit_fw of comp_BC (bc.gm:18-21):  v.sigma = Sum(w: v.UpNbrs){ w.sigma }
+__global__ void __launch_bounds__(BFS_THREADS)
+bc_forward_kernel(const int32_t* __restrict__ order, int64_t lo, int64_t hi, int32_t level, const int32_t* __restrict__ dist,
+                  const int32_t* __restrict__ r_begin, const int32_t* __restrict__ r_node_idx, int32_t skip, float* __restrict__ sigma) {
+    int64_t i = lo + (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < hi; i += stride) {
+        const int32_t v = order[i];
+        if (v == skip) continue;
+        float S1 = 0.0f;
+        for (int32_t w_idx = r_begin[v]; w_idx < r_begin[v + 1]; w_idx++) {
+            const int32_t w = r_node_idx[w_idx];
+            if (dist[w] != level - 1) continue;
+            S1 = S1 + sigma[w];
+        }
+        sigma[v] = S1;
+    }
+}
+
+// visit_rv (bc.gm:22-29):  v.delta = Sum(w: v.DownNbrs){ v.sigma / w.sigma * (1 + w.delta) };  v.BC += v.delta
+__global__ void __launch_bounds__(BFS_THREADS)
+bc_reverse_kernel(const int32_t* __restrict__ order, int64_t lo, int64_t hi, int32_t level, const int32_t* __restrict__ dist,
+                  const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx, int32_t skip,
+                  const float* __restrict__ sigma, float* __restrict__ delta, float* __restrict__ bc) {
+    int64_t i = lo + (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < hi; i += stride) {
+        const int32_t v = order[i];
+        if (v == skip) continue;
+        float S2 = 0.0f;
+        const float sv = sigma[v];
+        for (int32_t w_idx = begin[v]; w_idx < begin[v + 1]; w_idx++) {
+            const int32_t w = node_idx[w_idx];
+            if (dist[w] != level + 1) continue;   // !is_down_edge(w_idx)
+            S2 = S2 + sv / sigma[w] * (1 + delta[w]);
+        }
+        delta[v] = S2;
+        bc[v] = bc[v] + S2;
+    }
+}
+
+__global__ void fill_f32_kernel(float* __restrict__ p, int64_t n, float v, int64_t one_at, float one_v) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = i == one_at ? one_v : v;
+}
+
+extern "C" int gmx_bc(gmx_graph_t* g, const gmx_node_t* seeds, int32_t nseeds, int skip_root, float* bc_host, gmx_stats_t* stats) {
+    GMX_REQUIRE(g && bc_host && (seeds || nseeds == 0) && nseeds >= 0, "bad argument");
+    GMX_REQUIRE(g->has_reverse, "comp_BC needs the reverse CSR (UpNbrs)");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    const int64_t V = g->V;
+    if (V == 0) return GMX_OK;
+    for (int32_t i = 0; i < nseeds; i++) GMX_REQUIRE(seeds[i] >= 0 && seeds[i] < V, "seed %d out of range", seeds[i]);
+    if (!g->bfs_cache) GMX_CHECK(gmx_bfs_create(g, 0, 1, &g->bfs_cache));
+    gmx_bfs* b = g->bfs_cache;
+    dbuf<float> sigma, delta, bc;
+    GMX_CHECK(sigma.alloc((size_t) V));
+    GMX_CHECK(delta.alloc((size_t) V));
+    GMX_CHECK(bc.alloc((size_t) V));
+    bfs_order ord;
+    ev_guard e0, e1;
+    GMX_CHECK(e0.create());
+    GMX_CHECK(e1.create());
+    GMX_HIP(hipEventRecord(e0.e, 0));
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, bc.p, V, 0.0f, (int64_t) -1, 0.0f);   // G.BC = 0
+    int64_t reached = 0;
+    for (int32_t si = 0; si < nseeds; si++) {   // For (s: Seeds.Items): sequential, as emitted
+        const gmx_node_t s = seeds[si];
+        hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, sigma.p, V, 0.0f, (int64_t) s, 1.0f);   // G.sigma = 0; s.sigma = 1
+        GMX_CHECK(bfs_run(b, s));
+        GMX_CHECK(bfs_make_order(b, &ord));
+        reached += ord.h_off[(size_t) ord.levels];
+        const int32_t skip = skip_root ? s : -1;
+        for (int32_t l = 0; l < ord.levels; l++) {
+            const int64_t lo = ord.h_off[(size_t) l], hi = ord.h_off[(size_t) l + 1];
+            if (hi > lo)
+                hipLaunchKernelGGL(bc_forward_kernel, dim3(grid_for(hi - lo)), dim3(BFS_THREADS), 0, 0, (const int32_t*) ord.order.p, lo, hi, l,
+                                   (const int32_t*) b->dist.p, g->r_begin.p, g->r_node_idx.p, skip, sigma.p);
+        }
+        for (int32_t l = ord.levels - 1; l >= 0; l--) {
+            const int64_t lo = ord.h_off[(size_t) l], hi = ord.h_off[(size_t) l + 1];
+            if (hi > lo)
+                hipLaunchKernelGGL(bc_reverse_kernel, dim3(grid_for(hi - lo)), dim3(BFS_THREADS), 0, 0, (const int32_t*) ord.order.p, lo, hi, l,
+                                   (const int32_t*) b->dist.p, g->begin.p, g->node_idx.p, skip, (const float*) sigma.p, delta.p, bc.p);
+        }
+        GMX_HIP(hipGetLastError());
+    }
+    GMX_HIP(hipEventRecord(e1.e, 0));
+    GMX_HIP(hipEventSynchronize(e1.e));
+    GMX_HIP(hipMemcpy(bc_host, bc.p, sizeof(float) * (size_t) V, hipMemcpyDeviceToHost));
+    if (stats) {
+        float ms = 0;
+        (void) hipEventElapsedTime(&ms, e0.e, e1.e);
+        stats->iterations = nseeds;
+        stats->kernel_ms = ms;
+        stats->vertices_reached = reached;
+    }
+    return GMX_OK;
+}
+
+// prepare(root) + do_bfs_forward() alone: every vertex's level as the template keeps it (level_t = short, unvisited
+// vertices hold __INVALID_LEVEL = -2, gm_bfs_template.h:725) and the number of levels
+__global__ void bfs_level_short_kernel(const int32_t* __restrict__ dist, int64_t V, int16_t* __restrict__ level) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < V; i += stride) level[i] = dist[i] == INT_MAX ? (int16_t) -2 : (int16_t) dist[i];
+}
+
+extern "C" int gmx_bfs_levels(gmx_graph_t* g, gmx_node_t root, int16_t* level_host, int32_t* nlevels) {
+    GMX_REQUIRE(g && level_host, "NULL argument");
+    if (nlevels) *nlevels = 0;
+    const int64_t V = g->V;
+    if (V == 0) return GMX_OK;
+    GMX_REQUIRE(root >= 0 && root < V, "root %d out of range", root);
+    if (!g->bfs_cache) GMX_CHECK(gmx_bfs_create(g, 0, 1, &g->bfs_cache));
+    gmx_bfs* b = g->bfs_cache;
+    GMX_CHECK(bfs_run(b, root));
+    GMX_REQUIRE(b->level < 32767, "%d levels do not fit level_t = short", b->level);
+    dbuf<int16_t> lv;
+    GMX_CHECK(lv.alloc((size_t) V));
+    hipLaunchKernelGGL(bfs_level_short_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, (const int32_t*) b->dist.p, V, lv.p);
+    GMX_HIP(hipMemcpy(level_host, lv.p, sizeof(int16_t) * (size_t) V, hipMemcpyDeviceToHost));
+    if (nlevels) *nlevels = b->level;
+    return GMX_OK;
+}
+
 // ------------------------------------------------------------------ avg_teen_cnt, conduct
 // Count-reductions over neighbours with an integer node property (/root/reference/apps/src/avg_teen_cnt.gm,
 // conduct.gm).  Both are "expand the out-edges of the vertices that pass a filter and do something per edge":

@@ -44,7 +44,7 @@ EXPORTS = [
     "gmx_last_error", "gmx_device_count", "gmx_set_device", "gmx_device_info", "gmx_copy_bandwidth",
     "gmx_graph_upload", "gmx_graph_from_edges", "gmx_graph_create_rmat", "gmx_graph_free", "gmx_graph_symmetrize",
     "gmx_graph_num_nodes", "gmx_graph_num_edges", "gmx_graph_download", "gmx_graph_edge_order",
-    "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_sssp", "gmx_avg_teen_cnt", "gmx_conduct", "gmx_triangle_counting", "gmx_triangle_counting_part", "gmx_graph_reverse_edge_map",
+    "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_bfs_levels", "gmx_bc", "gmx_sssp", "gmx_avg_teen_cnt", "gmx_conduct", "gmx_triangle_counting", "gmx_triangle_counting_part", "gmx_graph_reverse_edge_map",
     "gmx_bfs_create", "gmx_bfs_free", "gmx_bfs_start", "gmx_bfs_step_begin", "gmx_bfs_found_bitmap", "gmx_bfs_step_end",
     "gmx_bfs_download",
     "gmx_pr_create", "gmx_pr_free", "gmx_pr_reset", "gmx_pr_step", "gmx_pr_contrib_slice",
@@ -94,6 +94,8 @@ def lib():
         L.gmx_pagerank_f64.argtypes = [vp, C.c_double, C.c_double, i32, vp, C.POINTER(Stats)]
         L.gmx_pagerank_f32.argtypes = [vp, C.c_float, C.c_float, i32, vp, C.POINTER(Stats)]
         L.gmx_hop_dist.argtypes = [vp, i32, vp, C.POINTER(Stats)]
+        L.gmx_bfs_levels.argtypes = [vp, i32, vp, C.POINTER(i32)]
+        L.gmx_bc.argtypes = [vp, vp, i32, C.c_int, vp, C.POINTER(Stats)]
         L.gmx_triangle_counting.argtypes = [vp, C.POINTER(i64), C.POINTER(Stats)]
         L.gmx_sssp.argtypes = [vp, i32, vp, vp, C.POINTER(Stats)]
         L.gmx_avg_teen_cnt.argtypes = [vp, vp, i32, vp, C.POINTER(C.c_float), C.POINTER(Stats)]
@@ -276,6 +278,21 @@ class Graph:
         st = Stats()
         _ck(lib().gmx_hop_dist(self._h, root, dist.ctypes.data, C.byref(st)))
         return dist, st.as_dict()
+
+    def bfs_levels(self, root=0):
+        """prepare(root) + do_bfs_forward() of the BFS object -> (level[int16], unvisited = -2; number of levels)."""
+        lv = np.zeros(max(self.V, 1), np.int16)[:self.V].copy()
+        n = C.c_int32(0)
+        _ck(lib().gmx_bfs_levels(self._h, int(root), lv.ctypes.data, C.byref(n)))
+        return lv, n.value
+
+    def bc(self, seeds, skip_root=False):
+        """comp_BC(G, BC, Seeds) of bc.gm -> (BC[float32], stats)."""
+        seeds = _i32(seeds)
+        out = np.zeros(max(self.V, 1), np.float32)[:self.V].copy()
+        st = Stats()
+        _ck(lib().gmx_bc(self._h, seeds.ctypes.data if len(seeds) else None, len(seeds), int(bool(skip_root)), out.ctypes.data, C.byref(st)))
+        return out, st.as_dict()
 
     def sssp(self, length, root=0):
         """sssp(G, dist, len, root): length[E] int32 by forward edge slot -- returns (dist[int32], stats)."""

@@ -148,6 +148,18 @@ int gmx_bfs_found_bitmap(gmx_bfs_t* b, void** words, int64_t* total_words, int64
 int gmx_bfs_step_end(gmx_bfs_t* b, int64_t* next_count);
 int gmx_bfs_download(gmx_bfs_t* b, int32_t* dist_host, gmx_stats_t* stats);
 
+/* The BFS object of `InBFS(v: G.Nodes From s) {..} InReverse {..}` (gm_bfs_template.h:14-312 as instantiated by
+ * gm_cpp_gen_bfs.cc:88-275: level_t = short, save_child when DownNbrs is used).
+ * gmx_bfs_levels = prepare(root) + do_bfs_forward(): level_host[V] as the template's visited_level (unvisited = -2,
+ * gm_bfs_template.h:725), *nlevels = deepest level + 1.
+ * gmx_bc = comp_BC(G, BC, Seeds) of apps/src/bc.gm (driver apps/output_cpp/src/bc_main.cc:43): for every seed, the
+ * traversal, visit_fw (sigma = Sum over UpNbrs) level by level, visit_rv (delta = Sum over DownNbrs, BC += delta)
+ * deepest level first; Float properties, every Sum added in row-slot order.  skip_root = 0 is this fork's bc.gm (the
+ * root is visited like any vertex, so its sigma = 1 is overwritten by an empty sum: all sigma 0, NaN wherever a
+ * reached vertex has a BFS child); skip_root = 1 is upstream Green-Marl's `(v != s)` form.  bc_host[V] is written. */
+int gmx_bfs_levels(gmx_graph_t* g, gmx_node_t root, int16_t* level_host, int32_t* nlevels);
+int gmx_bc(gmx_graph_t* g, const gmx_node_t* seeds, int32_t nseeds, int skip_root, float* bc_host, gmx_stats_t* stats);
+
 /* sssp(G, dist, len, root) (apps/src/sssp.gm; driver apps/output_cpp/src/sssp_main.cc:42): shortest path lengths
  * over out-edges with the caller's edge property len[E] (indexed by forward edge slot), INT_MAX = unreachable.
  * stats: iterations = relaxation rounds, h2d_ms = upload of len, vertices_reached = queue entries over all rounds. */

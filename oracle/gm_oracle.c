@@ -521,6 +521,86 @@ void gmo_hop_dist(gmo_node_t numNodes,
     if (levels_out) *levels_out = levels;
 }
 
+/* ------------------------------------------------------------------ */
+/* comp_BC (betweenness centrality estimate over a seed sequence)      */
+/*   source apps/src/bc.gm:4-31.  `InBFS(v: G.Nodes From s)` becomes a   */
+/*   subclass of gm_bfs_template<short, omp, false, false, true>        */
+/*   (src/backend_cpp/gm_cpp_gen_bfs.cc:88-221: level_t = short,        */
+/*   save_child because DownNbrs is used) whose visit_fw / visit_rv     */
+/*   hold the loop bodies, driven by prepare(s) / do_bfs_forward() /    */
+/*   do_bfs_reverse() (:256-265; gm_bfs_template.h:44-312).             */
+/*   `v.UpNbrs`  -> loop over the REVERSE row of v with                 */
+/*        if (get_level(w) != (get_curr_level() - 1)) continue;         */
+/*   `v.DownNbrs`-> loop over the forward row of v with                 */
+/*        if (!is_down_edge(w_idx)) continue;                           */
+/*   (gm_cpp_gen_foreach.cc:161-176); an edge v->u is a down edge iff   */
+/*   level(u) == level(v) + 1 (gm_bfs_template.h:581-622).  Both loops  */
+/*   walk edge SLOTS, so repeated edges count repeatedly.  Sum over     */
+/*   Float -> a float accumulator, terms added in row order             */
+/*   (src/opt/gm_syntax_sugar2.cc:182-330); `v.BC += v.delta @ s`       */
+/*   is applied to v itself.  visit_fw / visit_rv run for EVERY vertex  */
+/*   of a level, the root included: this fork's bc.gm has no            */
+/*   `(v != s)` filter (upstream Green-Marl's has), so the forward      */
+/*   visit of s overwrites s.sigma = 1 with the empty sum 0, every      */
+/*   sigma stays 0 and every reached vertex with a BFS child gets       */
+/*   0/0 = NaN.  skip_root = 1 gives the upstream form (both filters).  */
+/*   Temporaries sigma / delta come from gm_rt_allocate_float           */
+/*   (uninitialised; delta is only read where it was written).          */
+/* ------------------------------------------------------------------ */
+void gmo_bc(gmo_node_t N, const gmo_edge_t* begin, const gmo_node_t* node_idx,
+            const gmo_edge_t* r_begin, const gmo_node_t* r_node_idx,
+            const gmo_node_t* seeds, int32_t nseeds, int skip_root, float* G_BC) {
+    size_t n = (size_t) (N > 0 ? N : 1);
+    float* G_sigma = (float*) malloc(sizeof(float) * n);
+    float* G_delta = (float*) malloc(sizeof(float) * n);
+    int32_t* level = (int32_t*) malloc(sizeof(int32_t) * n);
+    gmo_node_t* order = (gmo_node_t*) malloc(sizeof(gmo_node_t) * n);   /* BFS order: levels are contiguous */
+    for (gmo_node_t t0 = 0; t0 < N; t0++) G_BC[t0] = 0;
+    for (int32_t si = 0; si < nseeds; si++) {
+        const gmo_node_t s = seeds[si];
+        for (gmo_node_t t1 = 0; t1 < N; t1++) G_sigma[t1] = 0;
+        G_sigma[s] = 1;
+        /* levels: the template's traversal order inside a level does not matter for a per-vertex visit */
+        for (gmo_node_t i = 0; i < N; i++) level[i] = -2;                /* __INVALID_LEVEL, gm_bfs_template.h:725 */
+        size_t head = 0, tail = 0;
+        level[s] = 0;
+        order[tail++] = s;
+        while (head < tail) {
+            gmo_node_t v = order[head++];
+            for (gmo_edge_t e = begin[v]; e < begin[v + 1]; e++) {
+                gmo_node_t u = node_idx[e];
+                if (level[u] == -2) { level[u] = level[v] + 1; order[tail++] = u; }
+            }
+        }
+        /* forward: visit_fw(v) for every v, level by level */
+        for (size_t i = 0; i < tail; i++) {
+            gmo_node_t v = order[i];
+            if (skip_root && v == s) continue;
+            float __S1 = 0;
+            for (gmo_edge_t w_idx = r_begin[v]; w_idx < r_begin[v + 1]; w_idx++) {
+                gmo_node_t w = r_node_idx[w_idx];
+                if (level[w] != (level[v] - 1)) continue;
+                __S1 = __S1 + G_sigma[w];
+            }
+            G_sigma[v] = __S1;
+        }
+        /* reverse: visit_rv(v), deepest level first */
+        for (size_t i = tail; i-- > 0;) {
+            gmo_node_t v = order[i];
+            if (skip_root && v == s) continue;
+            float __S2 = 0;
+            for (gmo_edge_t w_idx = begin[v]; w_idx < begin[v + 1]; w_idx++) {
+                gmo_node_t w = node_idx[w_idx];
+                if (level[w] != level[v] + 1) continue;                /* !is_down_edge(w_idx) */
+                __S2 = __S2 + G_sigma[v] / G_sigma[w] * (1 + G_delta[w]);
+            }
+            G_delta[v] = __S2;
+            G_BC[v] = G_BC[v] + G_delta[v];
+        }
+    }
+    free(G_sigma); free(G_delta); free(level); free(order);
+}
+
 void gmo_bfs_queue(gmo_node_t N,
                    const gmo_edge_t* begin, const gmo_node_t* node_idx,
                    gmo_node_t root, int32_t* dist) {

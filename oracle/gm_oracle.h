@@ -107,6 +107,11 @@ void gmo_hop_dist(gmo_node_t N,
 
 /* Independent second statement of the same result: plain queue BFS.
  * Used only to cross-check gmo_hop_dist. */
+/* comp_BC of apps/src/bc.gm (skip_root: upstream's `(v != s)` filters) */
+void gmo_bc(gmo_node_t N, const gmo_edge_t* begin, const gmo_node_t* node_idx,
+            const gmo_edge_t* r_begin, const gmo_node_t* r_node_idx,
+            const gmo_node_t* seeds, int32_t nseeds, int skip_root, float* G_BC);
+
 void gmo_bfs_queue(gmo_node_t N,
                    const gmo_edge_t* begin, const gmo_node_t* node_idx,
                    gmo_node_t root, int32_t* dist);

@@ -50,6 +50,7 @@ def ref_lib():
     R.ref_rmat_csr.argtypes = [C.c_int32, C.c_int32, C.c_long, C.c_double, C.c_double, C.c_double, C.c_int, i32p, i32p]
     R.ref_prepare.argtypes = [C.c_int32, C.c_int32, i32p, i32p, i32p, i32p, i32p]
     R.ref_store_binary.argtypes = [C.c_char_p, C.c_int32, C.c_int32, i32p, i32p]
+    R.ref_bc.argtypes = [C.c_int32, C.c_int32, i32p, i32p, i32p, C.c_int32, C.c_int, np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.c_int]
     R.ref_load_adj.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), i32p, i32p, C.c_int32, C.c_int32]
     R.ref_load_binary.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -168,6 +169,93 @@ def check_counts(R, name, g, salt):
     return out, avgs, cs
 
 
+def bc_seeds(N, root):
+    """Five seeds like the driver's (bc_main.cc:34-41 draws 5), fixed here: root, a few spread ones, the last vertex."""
+    return np.array([root % N, (root + N // 3) % N, (7 * root + 5) % N, N - 1, N // 2], np.int32)
+
+
+def canon_nan(a):
+    """NaN payload / sign is the platform's (x86 SSE: the negative default NaN); compare NaN as NaN."""
+    a = a.copy()
+    a[np.isnan(a)] = np.float32(np.nan)
+    return a
+
+
+def brandes_f64(g, seeds):
+    """Second opinion for comp_BC's upstream form, independent of both the oracle and the reference: Brandes'
+    dependency accumulation with path counts per edge SLOT (repeated edges count repeatedly, as both emitted loops
+    do), plain Python, float64."""
+    N = g.N
+    bc = np.zeros(N, np.float64)
+    begin, idx = g.begin, g.node_idx
+    for s in seeds:
+        level = np.full(N, -2, np.int64)
+        sigma = np.zeros(N, np.float64)
+        delta = np.zeros(N, np.float64)
+        level[s], sigma[s] = 0, 1.0
+        order, frontier = [int(s)], [int(s)]
+        while frontier:
+            nxt = []
+            for v in frontier:
+                for u in idx[begin[v]:begin[v + 1]]:
+                    if level[u] == -2:
+                        level[u] = level[v] + 1
+                        nxt.append(int(u))
+            for v in frontier:                      # every slot into the next level carries v's path count
+                for u in idx[begin[v]:begin[v + 1]]:
+                    if level[u] == level[v] + 1:
+                        sigma[u] += sigma[v]
+            order += nxt
+            frontier = nxt
+        for v in reversed(order):
+            if v == s:
+                continue
+            acc = 0.0
+            for u in idx[begin[v]:begin[v + 1]]:
+                if level[u] == level[v] + 1:
+                    acc += sigma[v] / sigma[u] * (1.0 + delta[u])
+            delta[v] = acc
+            bc[v] += acc
+    return bc
+
+
+def check_bc(R, name, g, root):
+    """comp_BC: the oracle restatement against (1) the emitted visit bodies on the reference's gm_bfs_template
+    (traversal, levels, is_down_edge and both sweeps are pure reference code), run single-threaded exactly as
+    emitted, and (2) an independent float64 Brandes for the upstream form.  (1) must agree bit for bit unless the
+    template went bottom-up (ST_RD -> ST_RRD, gm_bfs_template.h:400-403: taken even with save_child), where it
+    records no down edges and its BC is too small; those cases are listed in the manifest and rest on (2)."""
+    seeds = bc_seeds(g.N, root)
+    out = {"bc_seeds": seeds}
+    for skip, key in ((0, "bc"), (1, "bc_skip_root")):
+        # one thread only: with several, iterate_neighbor_que sets a child's visited bit before it stores the child's
+        # level (gm_bfs_template.h:596-620), and a second parent that runs in between finds the bit set, reads a
+        # stale level and does not record its down edge -- the reference's multi-threaded DownNbrs (hence BC) varies
+        # from run to run (seen on rmat10_perm).  The single-threaded run is the deterministic definition.
+        emitted = np.zeros(g.N, np.float32)
+        assert R.ref_bc(g.N, g.M, g.begin, g.node_idx, seeds, len(seeds), skip, emitted, 1) == 0
+        got = po.bc(g, seeds, bool(skip))
+        same = canon_nan(got).tobytes() == canon_nan(emitted).tobytes()
+        out[key + "_reference_equal"] = bool(same)
+        if not same:
+            # never more than the definition gives: the reference only loses down edges
+            ok = ~np.isnan(got) & ~np.isnan(emitted)
+            assert np.all(emitted[ok] <= got[ok] * (1 + 1e-5) + 1e-30), (name, key, "reference larger than the definition")
+            print("  %s %s: the reference's template went bottom-up and dropped down edges (%d of %d values differ)"
+                  % (name, key, int(np.sum(canon_nan(got) != canon_nan(emitted)) - np.sum(np.isnan(got) & np.isnan(emitted))), g.N))
+        if skip and g.N <= (1 << 12):
+            ref64 = brandes_f64(g, seeds)
+            assert not np.isnan(got).any(), (name, key, "NaN in the upstream form")
+            err = np.abs(got.astype(np.float64) - ref64) / np.maximum(np.abs(ref64), 1e-30)
+            assert float(err[ref64 > 0].max(initial=0.0)) < 2e-4 and np.all(got[ref64 == 0] == 0), (name, key, "Brandes", float(err.max()))
+        out[key] = canon_nan(got)
+    return out
+
+
+def bc_arrays(bcs):
+    return {k: v for k, v in bcs.items() if isinstance(v, np.ndarray)}
+
+
 def check_oracle_on(R, name, N, begin, raw_or_sorted, pr_args=(0.001, 0.85, 100), root=0, tc=True):
     """Run reference + oracle on one CSR; assert agreement; return results."""
     g = po.Graph(N, begin.copy(), raw_or_sorted.copy()).prepare()
@@ -254,6 +342,7 @@ def main():
                           for s, t in zip(qs, qt)], np.int32)
         assert np.array_equal(out_o, out_r), (name, "is_neighbor")
 
+        bcs = check_bc(R, name, g, root) if scale <= 14 else None
         entry = {"N": N, "M": M, "seed": 1997, "abc": [0.57, 0.19, 0.19], "permute": perm, "attempts": att,
                  "root": root, "pr_iters": it, "tc_directed": T, "tc_symmetrized": Ts, "M_sym": gs.M,
                  "reached": int((dist != INT_MAX).sum()), "max_level": int(dist[dist != INT_MAX].max()),
@@ -265,11 +354,15 @@ def main():
                  "sssp_salt": scale * 2 + perm, "sha_sssp_len": sha(sssp_len), "sha_sssp_dist": sha(sssp_dist),
                  "sssp_reached": int((sssp_dist != INT_MAX).sum()), "sssp_max": int(sssp_dist[sssp_dist != INT_MAX].max()),
                  "rank_sum": float(rank.sum()), "rank_head": [float(x) for x in rank[:4]]}
+        if bcs is not None:
+            entry.update({"bc_seeds": [int(x) for x in bcs["bc_seeds"]], "sha_bc": sha(bcs["bc"]), "sha_bc_skip_root": sha(bcs["bc_skip_root"]),
+                          "bc_nan": int(np.isnan(bcs["bc"]).sum()), "bc_skip_root_nan": int(np.isnan(bcs["bc_skip_root"]).sum()),
+                          "bc_reference_equal": [bcs["bc_reference_equal"], bcs["bc_skip_root_reference_equal"]]})
         manifest["rmat"][name] = entry
         if scale <= 10:   # small enough to commit in full
             fixtures[name] = dict(begin=begin, raw_node_idx=raw, node_idx=snode, r_begin=rb, r_node_idx=rn,
                                   rank=rank, rank20=rank20, dist=dist, sssp_len=sssp_len, sssp_dist=sssp_dist,
-                                  age=props["age"], member=props["member"], teen_cnt=props["teen_cnt"])
+                                  age=props["age"], member=props["member"], teen_cnt=props["teen_cnt"], **bc_arrays(bcs))
         print("%s: pinned (iters=%d, reached=%d, T=%s, Tsym=%s)" % (name, it, entry["reached"], T, Ts))
 
     # ---- 3. hand graphs ----
@@ -304,9 +397,10 @@ def main():
         g, rank, it, dist, T = check_oracle_on(R, name, N, begin, raw, root=root, tc=True)
         sssp_len, sssp_dist = check_sssp(R, name, g, root, len(name))
         props, teen_avgs, conducts = check_counts(R, name, g, len(name))
+        bcs = check_bc(R, name, g, root)
         fixtures["hand_" + name] = dict(begin=begin, raw_node_idx=raw, node_idx=g.node_idx, r_begin=g.r_begin,
                                         r_node_idx=g.r_node_idx, rank=rank, dist=dist, sssp_len=sssp_len, sssp_dist=sssp_dist,
-                                        age=props["age"], member=props["member"], teen_cnt=props["teen_cnt"])
+                                        age=props["age"], member=props["member"], teen_cnt=props["teen_cnt"], **bc_arrays(bcs))
         manifest["hand"][name] = {"N": N, "M": len(edges), "root": root, "pr_iters": it, "tc": T,
                                   "teen_avg_K5_K25_K100": teen_avgs, "conduct_0_4": conducts}
         print("hand %s: pinned (iters=%d T=%d)" % (name, it, T))

@@ -14,6 +14,7 @@ _LIB = None
 
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 
 
 def build(force=False):
@@ -51,6 +52,8 @@ def lib():
         L.gmo_avg_teen_cnt.restype = C.c_float
         L.gmo_conduct.argtypes = [C.c_int32, i32p, i32p, i32p, C.c_int32, C.c_int]
         L.gmo_conduct.restype = C.c_float
+        L.gmo_bc.argtypes = [C.c_int32, i32p, i32p, i32p, i32p, i32p, C.c_int32, C.c_int, f32p]
+        L.gmo_bc.restype = None
         L.gmo_bfs_queue.argtypes = [C.c_int32, i32p, i32p, C.c_int32, i32p]
         L.gmo_bfs_queue.restype = None
         L.gmo_triangle_counting.argtypes = [C.c_int32, i32p, i32p, C.c_int]
@@ -185,6 +188,14 @@ def conduct(g, member, num, nthreads=0):
     """conduct(G, member, num) -> float32."""
     member = np.ascontiguousarray(member, np.int32)
     return np.float32(lib().gmo_conduct(g.N, g.begin, g.node_idx, member, int(num), nthreads))
+
+
+def bc(g, seeds, skip_root=False):
+    """comp_BC of apps/src/bc.gm over the seed sequence -> float32 BC[N] (skip_root: upstream's (v != s) filters)."""
+    seeds = np.ascontiguousarray(seeds, np.int32)
+    out = np.zeros(max(g.N, 1), np.float32)
+    lib().gmo_bc(g.N, g.begin, g.node_idx, g.r_begin, g.r_node_idx, seeds, len(seeds), int(bool(skip_root)), out)
+    return out[:g.N]
 
 
 def bfs_queue(g, root=0):

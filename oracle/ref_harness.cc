@@ -433,6 +433,90 @@ int ref_bfs_levels(int32_t N, int32_t M, const int32_t* begin, const int32_t* no
     return 0;
 }
 
+/* ---- comp_BC (apps/src/bc.gm): the traversal, the level bookkeeping, is_down_edge and the forward / reverse
+ *      sweeps are the reference's gm_bfs_template<short, true, false, false, true> (save_child: DownNbrs is used,
+ *      gm_cpp_gen_bfs.cc:88-98); visit_fw / visit_rv are the emitted loop bodies (gm_cpp_gen_foreach.cc:161-176). ---- */
+class ref_bc_bfs_t : public gm_bfs_template<short, true, false, false, true>
+{
+  public:
+    // _T: the graph object the template traverses; _G: the graph whose rows the visit bodies walk (the same graph;
+    // two objects only so that the traversal can be run without reverse edges, see ref_bc)
+    ref_bc_bfs_t(gm_graph& _T, gm_graph& _G, float*& _G_sigma, float*& _G_delta, float*& _G_BC, node_t& _s, int _skip_root)
+        : gm_bfs_template<short, true, false, false, true>(_T), G(_G), G_sigma(_G_sigma), G_delta(_G_delta), G_BC(_G_BC),
+          s(_s), skip_root(_skip_root) {}
+  private:
+    gm_graph& G;
+    float*& G_sigma;
+    float*& G_delta;
+    float*& G_BC;
+    node_t& s;
+    int skip_root;
+  protected:
+    virtual void visit_fw(node_t v) {
+        if (skip_root && v == s) return;   /* upstream's InBFS(...)(v != s) */
+        float __S1 = ((float) (0.000000));
+        for (edge_t w_idx = G.r_begin[v]; w_idx < G.r_begin[v + 1]; w_idx++) {
+            node_t w = G.r_node_idx[w_idx];
+            if (get_level(w) != (get_curr_level() - 1)) continue;
+            __S1 = __S1 + G_sigma[w];
+        }
+        G_sigma[v] = __S1;
+    }
+    virtual void visit_rv(node_t v) {
+        if (skip_root && v == s) return;
+        float __S2 = ((float) (0.000000));
+        for (edge_t w_idx = G.begin[v]; w_idx < G.begin[v + 1]; w_idx++) {
+            node_t w = G.node_idx[w_idx];
+            if (!is_down_edge(w_idx)) continue;
+            __S2 = __S2 + G_sigma[v] / G_sigma[w] * (1 + G_delta[w]);
+        }
+        G_delta[v] = __S2;
+        G_BC[v] = G_BC[v] + G_delta[v];
+    }
+    virtual bool check_navigator(node_t v, edge_t v_idx) { return true; }
+};
+
+/* One graph object with reverse edges, exactly what the emission does.  Known defects of the reference on this path,
+ * all in gm_bfs_template.h: (1) the template may switch to its bottom-up state (ST_RD -> ST_RRD, :400-403 -- that
+ * transition lacks the `!save_child` guard the other two have, :374,389), where a vertex stops at its first parent and
+ * NO down edges are recorded (check_parent_rrd :689-708): DownNbrs then silently misses edges and BC comes out too
+ * small (the same transition also lacks the has_reverse_edge() guard, so a graph without reverse edges crashes
+ * there); (2) with several threads a down edge is lost when a second parent sees the child's visited bit before the
+ * first has stored the child's level (:596-620); (3) the destructor, see below. */
+int ref_bc(int32_t N, int32_t M, const int32_t* begin, const int32_t* node_idx, const int32_t* seeds, int32_t nseeds,
+           int skip_root, float* G_BC, int nthreads) {
+    gm_graph* gp = make_graph(N, M, begin, node_idx);
+    gm_graph& G = *gp;
+    gm_rt_set_num_threads(nthreads);
+    gm_rt_initialize();
+    G.freeze();
+    G.do_semi_sort();
+    G.make_reverse_edges();
+    gm_graph* tp = gp;
+    float* G_sigma = gm_rt_allocate_float(G.num_nodes(), gm_rt_thread_id());
+    float* G_delta = gm_rt_allocate_float(G.num_nodes(), gm_rt_thread_id());
+    #pragma omp parallel for
+    for (node_t t0 = 0; t0 < G.num_nodes(); t0++) G_BC[t0] = 0;
+    for (int32_t i = 0; i < nseeds; i++) {
+        node_t s = seeds[i];
+        #pragma omp parallel for
+        for (node_t t1 = 0; t1 < G.num_nodes(); t1++) G_sigma[t1] = 0;
+        G_sigma[s] = 1;
+        /* The emission declares the BFS object on the stack.  With save_child its destructor does
+         * `delete [] down_edge_set` on a pointer that came from `new std::set<edge_t>()` (gm_bfs_template.h:30-31,40):
+         * glibc aborts ("free(): invalid pointer").  The harness therefore never destroys the object (a leak per
+         * seed in a test tool); everything it computes before that point is the reference's own code. */
+        ref_bc_bfs_t* _BFS = new ref_bc_bfs_t(*tp, G, G_sigma, G_delta, G_BC, s, skip_root);
+        _BFS->prepare(s, gm_rt_get_num_threads());
+        _BFS->do_bfs_forward();
+        _BFS->do_bfs_reverse();
+    }
+    gm_rt_cleanup();
+    if (tp != gp) delete tp;
+    delete gp;
+    return 0;
+}
+
 /* ---- triangle_counting: plain emission, HasEdgeTo through the reference's
  *      gm_graph::is_neighbor (gm_graph.cc:60-66,589-633) ---- */
 int64_t ref_triangle_counting(int32_t N, int32_t M, const int32_t* begin, const int32_t* node_idx, int nthreads) {

@@ -137,6 +137,45 @@ def test_hop_dist_golden(gmx, golden):
         g2.free()
 
 
+def same_f32(a, b):
+    """float32 arrays equal bit for bit, any NaN counting as NaN (its sign / payload is the platform's)."""
+    return np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32))
+
+
+def test_bfs_object_levels_and_bc_golden(gmx, golden):
+    """The device BFS object (gm_bfs_template's role for InBFS / InReverse): levels as the template keeps them
+    (short, unvisited -2; the fixtures' dist[] equals gm_bfs_template<short,...> levels, oracle/make_golden.py),
+    and comp_BC of bc.gm -- this fork's form (root visited: NaN pattern) and upstream's -- bit for bit against
+    the fixtures pinned on the reference's template."""
+    for name, c, m in host_graphs(golden):
+        g = gmx.Graph.upload(c["begin"], c["node_idx"], c["r_begin"], c["r_node_idx"])
+        lv, n = g.bfs_levels(m["root"])
+        want = np.where(c["dist"] == INT_MAX, -2, c["dist"]).astype(np.int16)
+        assert np.array_equal(lv, want) and n == int(want.max()) + 1, name
+        if "bc" in c:
+            assert same_f32(g.bc(c["bc_seeds"], False)[0], c["bc"]), name
+            got, st = g.bc(c["bc_seeds"], True)
+            assert same_f32(got, c["bc_skip_root"]), name
+            assert st["iterations"] == len(c["bc_seeds"])
+        g.free()
+
+
+@pytest.mark.parametrize("scale,permute", [(12, False), (14, True), (16, False), (18, True)])
+def test_bc_vs_oracle_larger(gmx, scale, permute):
+    """comp_BC on graphs where the traversal goes bottom-up (the compiled reference drops down edges there,
+    oracle/make_golden.py): bit-identical with the oracle restatement, which is pinned on the reference's template
+    wherever that records every down edge and cross-checked against a float64 Brandes up to scale 12."""
+    og = po.rmat_graph(scale, permute=permute)
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    rng = np.random.default_rng(scale)
+    seeds = np.concatenate([[int(np.argmax(np.diff(og.begin)))], rng.integers(0, og.N, 4)]).astype(np.int32)
+    for skip in (False, True):
+        got, st = g.bc(seeds, skip)
+        assert same_f32(got, po.bc(og, seeds, skip)), (scale, permute, skip)
+    assert not np.isnan(got).any() and float(got.max()) > 0
+    g.free()
+
+
 @pytest.mark.parametrize("scale,permute", [(16, False), (18, False), (18, True), (20, False)])
 def test_hop_dist_vs_oracle_larger(gmx, scale, permute):
     og = po.rmat_graph(scale, permute=permute)

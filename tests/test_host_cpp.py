@@ -65,7 +65,7 @@ def test_gm_graph_api(host_built, golden, tmp_path):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_APPS), reason="reference tree not present (GPU box)")
-@pytest.mark.parametrize("app", ["pagerank", "hop_dist", "triangle_counting", "sssp", "avg_teen_cnt", "conduct"])
+@pytest.mark.parametrize("app", ["pagerank", "hop_dist", "triangle_counting", "sssp", "avg_teen_cnt", "conduct", "bc"])
 def test_reference_drivers_compile_unchanged(host_built, tmp_path, app):
     """Drop-in check: the REFERENCE's own driver sources (common_main.h + <app>_main.cc), untouched and
     compiled where they lie, build and link against this repo's gm.h / generated headers / libraries."""

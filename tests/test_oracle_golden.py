@@ -39,6 +39,18 @@ def check_counts(g, c, m):
         assert np.float32(po.conduct(g, c["member"], num)) == np.float32(want)
 
 
+def same_f32(a, b):
+    """float32 arrays equal bit for bit, any NaN counting as NaN (its sign / payload is the platform's)."""
+    return np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32))
+
+
+def check_bc(g, c):
+    """comp_BC (bc.gm): this fork's form and upstream's, against the reference-pinned arrays."""
+    assert same_f32(po.bc(g, c["bc_seeds"], False), c["bc"])
+    assert same_f32(po.bc(g, c["bc_seeds"], True), c["bc_skip_root"])
+    assert not np.isnan(c["bc_skip_root"]).any()
+
+
 @pytest.mark.parametrize("name", ["rmat6_noperm", "rmat6_perm", "rmat8_noperm", "rmat8_perm",
                                   "rmat10_noperm", "rmat10_perm"])
 def test_rmat_fixture_full(golden, name):
@@ -60,6 +72,7 @@ def test_rmat_fixture_full(golden, name):
     assert np.array_equal(po.sssp(g, c["sssp_len"], m["root"])[0], c["sssp_dist"])
     assert sha(c["sssp_len"]) == m["sha_sssp_len"] and sha(c["sssp_dist"]) == m["sha_sssp_dist"]
     check_counts(g, c, m)
+    check_bc(g, c)
     assert po.triangle_counting(g) == m["tc_directed"]
     assert po.triangle_counting_merge(g) == m["tc_directed"]
     gs = po.symmetrize(g)
@@ -82,6 +95,12 @@ def test_rmat_fixture_hashed(golden, name):
     dist, _ = po.hop_dist(g, m["root"])
     assert sha(dist) == m["sha_dist"]
     assert int((dist != INT_MAX).sum()) == m["reached"]
+    if "sha_bc" in m:
+        seeds = np.array(m["bc_seeds"], np.int32)
+        for skip, key in ((False, "bc"), (True, "bc_skip_root")):
+            got = po.bc(g, seeds, skip)
+            got[np.isnan(got)] = np.float32(np.nan)
+            assert sha(got) == m["sha_" + key] and int(np.isnan(got).sum()) == m[key + "_nan"]
     if m["tc_directed"] is not None:
         assert po.triangle_counting_merge(g) == m["tc_directed"]
     assert po.triangle_counting_merge(po.symmetrize(g)) == m["tc_symmetrized"]
@@ -99,6 +118,7 @@ def test_hand_graphs(golden):
         assert np.array_equal(dist, c["dist"]), name
         assert np.array_equal(po.sssp(g, c["sssp_len"], m["root"])[0], c["sssp_dist"]), name
         check_counts(g, c, m)
+        check_bc(g, c)
         assert po.triangle_counting(g) == m["tc"], name
         assert po.triangle_counting_merge(g) == m["tc"], name
 
