@@ -411,11 +411,25 @@ static int tc_counting_graph(gmx_graph* g, gmx_graph** out, bool* oriented) {
     return GMX_OK;
 }
 
+static int tc_count_part(gmx_graph_t* g, int part, int nparts, bool common_nbr_form, int64_t* count, gmx_stats_t* stats);
+
 extern "C" int gmx_triangle_counting(gmx_graph_t* g, int64_t* count, gmx_stats_t* stats) {
-    return gmx_triangle_counting_part(g, 0, 1, count, stats);
+    return tc_count_part(g, 0, 1, false, count, stats);
 }
 
 extern "C" int gmx_triangle_counting_part(gmx_graph_t* g, int part, int nparts, int64_t* count, gmx_stats_t* stats) {
+    return tc_count_part(g, part, nparts, false, count, stats);
+}
+
+// triangle counting written with the common-neighbour iterator (gm_common_neighbor_iter.cc:21-44):
+//   Foreach(v: G.Nodes) Foreach(u: v.Nbrs)(u > v) Foreach(w: v.CommonNbrs(u))(w > u) T += 1;
+// w walks the slots of v's row (with multiplicity) and passes when it occurs in the FORWARD row of u -- the emitted
+// triangle_counting.gm asks for w -> u instead (HasEdgeTo), i.e. for the in-row of u.  Same kernels, other rows.
+extern "C" int gmx_triangle_counting_cn(gmx_graph_t* g, int64_t* count, gmx_stats_t* stats) {
+    return tc_count_part(g, 0, 1, true, count, stats);
+}
+
+static int tc_count_part(gmx_graph_t* g, int part, int nparts, bool common_nbr_form, int64_t* count, gmx_stats_t* stats) {
     GMX_REQUIRE(g && count, "NULL argument");
     GMX_REQUIRE(nparts >= 1 && part >= 0 && part < nparts, "bad part %d / nparts %d", part, nparts);
     if (stats) memset(stats, 0, sizeof(*stats));
@@ -427,6 +441,11 @@ extern "C" int gmx_triangle_counting_part(gmx_graph_t* g, int part, int nparts, 
     GMX_CHECK(tc_counting_graph(g, &cg, &oriented));
     const int32_t* rbeg = oriented ? cg->begin.p : g->r_begin.p;         // symmetric: the in-rows are the out-rows
     const int32_t* ridx = oriented ? cg->node_idx.p : g->r_node_idx.p;
+    if (common_nbr_form && !oriented) {   // membership in the forward row of u
+        rbeg = g->begin.p;
+        ridx = g->node_idx.p;
+    }
+    const bool have_rows = g->has_reverse || oriented || common_nbr_form;
     g = cg;
     // local slot indices of this part: whole deal blocks (slots past E are skipped in the kernels)
     const int64_t deal = (int64_t) 1 << TC_DEAL_SHIFT;
@@ -446,7 +465,7 @@ extern "C" int gmx_triangle_counting_part(gmx_graph_t* g, int part, int nparts, 
                            (const int32_t*) g->r_begin.p, (const int32_t*) g->r_node_idx.p, g->V, part, nparts,
                            TCO_ALONE, TCO_RATIO, ctr.p + 1, ctr.p);
         GMX_HIP(hipGetLastError());
-    } else if (g->has_reverse || oriented) {
+    } else if (have_rows) {
         dbuf<tc_pair> big;
         GMX_CHECK(big.alloc((size_t) nlocal));
         if (blocks > 256 * 64) blocks = 256 * 64;
@@ -483,5 +502,81 @@ extern "C" int gmx_triangle_counting_part(gmx_graph_t* g, int part, int nparts, 
         stats->iterations = 1;
         stats->kernel_ms = ms;
     }
+    return GMX_OK;
+}
+
+// ------------------------------------------------------------------ common-neighbour iterator
+// gm_common_neighbor_iter(G, s, d) (gm_common_neighbor_iter.cc:21-44; Foreach(u: s.CommonNbrs(d)) <=>
+// Foreach(u: s.Nbrs)(d.isNbr(u)), gm_common_neighbor_iter.h:11-17): the slots of s's row, in order and with their
+// multiplicity, whose value occurs in d's row.  Rows are semi-sorted.  One wave per pair: 64 slots of s's row at a
+// time, each lane looks its value up in d's row, a ballot keeps the order.
+__global__ void __launch_bounds__(TC_THREADS)
+common_nbr_count_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx,
+                        const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t npairs, int64_t* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    int64_t wave = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t) gridDim.x * blockDim.x) >> 6;
+    for (; wave < npairs; wave += nwaves) {
+        const int32_t s = src[wave], d = dst[wave];
+        const int32_t sb = begin[s], se = begin[s + 1], db = begin[d], de = begin[d + 1];
+        unsigned long long c = 0;
+        for (int32_t j = sb + lane; j < se; j += 64) c += tc_contains(node_idx, db, de, node_idx[j]) ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+        if (lane == 0) counts[wave] = (int64_t) c;
+    }
+}
+
+__global__ void __launch_bounds__(64)
+common_nbr_list_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx, int32_t s, int32_t d,
+                       int32_t* __restrict__ out, int64_t cap, int64_t* __restrict__ n_out) {
+    const int lane = threadIdx.x & 63;
+    const int32_t sb = begin[s], se = begin[s + 1], db = begin[d], de = begin[d + 1];
+    int64_t n = 0;
+    for (int32_t j0 = sb; j0 < se; j0 += 64) {
+        const int32_t j = j0 + lane;
+        const int32_t t = j < se ? node_idx[j] : 0;
+        const bool hit = j < se && tc_contains(node_idx, db, de, t);
+        const unsigned long long m = __ballot(hit);
+        const int64_t at = n + __builtin_popcountll(m & ((1ull << lane) - 1));
+        if (hit && at < cap) out[at] = t;
+        n += __builtin_popcountll(m);
+    }
+    if (lane == 0) *n_out = n;
+}
+
+extern "C" int gmx_common_nbr_counts(gmx_graph_t* g, const gmx_node_t* src, const gmx_node_t* dst, int64_t npairs, int64_t* counts) {
+    GMX_REQUIRE(g && counts && ((src && dst) || npairs == 0) && npairs >= 0, "bad argument");
+    if (npairs == 0) return GMX_OK;
+    for (int64_t i = 0; i < npairs; i++)
+        GMX_REQUIRE(src[i] >= 0 && src[i] < g->V && dst[i] >= 0 && dst[i] < g->V, "pair %lld: vertex out of range", (long long) i);
+    dbuf<int32_t> ds, dd;
+    dbuf<int64_t> dc;
+    GMX_CHECK(ds.alloc((size_t) npairs));
+    GMX_CHECK(dd.alloc((size_t) npairs));
+    GMX_CHECK(dc.alloc((size_t) npairs));
+    GMX_HIP(hipMemcpy(ds.p, src, sizeof(int32_t) * (size_t) npairs, hipMemcpyHostToDevice));
+    GMX_HIP(hipMemcpy(dd.p, dst, sizeof(int32_t) * (size_t) npairs, hipMemcpyHostToDevice));
+    int64_t blocks = (npairs * 64 + TC_THREADS - 1) / TC_THREADS;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(common_nbr_count_kernel, dim3((unsigned) blocks), dim3(TC_THREADS), 0, 0, g->begin.p, g->node_idx.p,
+                       (const int32_t*) ds.p, (const int32_t*) dd.p, npairs, dc.p);
+    GMX_HIP(hipGetLastError());
+    GMX_HIP(hipMemcpy(counts, dc.p, sizeof(int64_t) * (size_t) npairs, hipMemcpyDeviceToHost));
+    return GMX_OK;
+}
+
+extern "C" int gmx_common_nbrs(gmx_graph_t* g, gmx_node_t s, gmx_node_t d, gmx_node_t* out, int64_t cap, int64_t* n) {
+    GMX_REQUIRE(g && n && (out || cap == 0) && cap >= 0, "bad argument");
+    GMX_REQUIRE(s >= 0 && s < g->V && d >= 0 && d < g->V, "vertex out of range");
+    dbuf<int32_t> dout;
+    dbuf<int64_t> dn;
+    GMX_CHECK(dout.alloc((size_t) (cap ? cap : 1)));
+    GMX_CHECK(dn.alloc(1));
+    hipLaunchKernelGGL(common_nbr_list_kernel, dim3(1), dim3(64), 0, 0, g->begin.p, g->node_idx.p, s, d, dout.p, cap, dn.p);
+    GMX_HIP(hipGetLastError());
+    GMX_HIP(hipMemcpy(n, dn.p, sizeof(int64_t), hipMemcpyDeviceToHost));
+    const int64_t m = *n < cap ? *n : cap;
+    if (m > 0) GMX_HIP(hipMemcpy(out, dout.p, sizeof(int32_t) * (size_t) m, hipMemcpyDeviceToHost));
     return GMX_OK;
 }

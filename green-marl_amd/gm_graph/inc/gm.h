@@ -11,4 +11,5 @@
 #include "gm_runtime.h"
 #include "gm_rand.h"
 #include "gm_seq.h"
+#include "gm_common_neighbor_iter.h"
 #endif

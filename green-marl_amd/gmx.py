@@ -44,7 +44,7 @@ EXPORTS = [
     "gmx_last_error", "gmx_device_count", "gmx_set_device", "gmx_device_info", "gmx_copy_bandwidth",
     "gmx_graph_upload", "gmx_graph_from_edges", "gmx_graph_create_rmat", "gmx_graph_free", "gmx_graph_symmetrize",
     "gmx_graph_num_nodes", "gmx_graph_num_edges", "gmx_graph_download", "gmx_graph_edge_order",
-    "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_bfs_levels", "gmx_bc", "gmx_sssp", "gmx_avg_teen_cnt", "gmx_conduct", "gmx_triangle_counting", "gmx_triangle_counting_part", "gmx_graph_reverse_edge_map",
+    "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_bfs_levels", "gmx_bc", "gmx_sssp", "gmx_avg_teen_cnt", "gmx_conduct", "gmx_triangle_counting", "gmx_triangle_counting_part", "gmx_triangle_counting_cn", "gmx_common_nbrs", "gmx_common_nbr_counts", "gmx_graph_reverse_edge_map",
     "gmx_bfs_create", "gmx_bfs_free", "gmx_bfs_start", "gmx_bfs_step_begin", "gmx_bfs_found_bitmap", "gmx_bfs_step_end",
     "gmx_bfs_download",
     "gmx_pr_create", "gmx_pr_free", "gmx_pr_reset", "gmx_pr_step", "gmx_pr_contrib_slice",
@@ -94,6 +94,9 @@ def lib():
         L.gmx_pagerank_f64.argtypes = [vp, C.c_double, C.c_double, i32, vp, C.POINTER(Stats)]
         L.gmx_pagerank_f32.argtypes = [vp, C.c_float, C.c_float, i32, vp, C.POINTER(Stats)]
         L.gmx_hop_dist.argtypes = [vp, i32, vp, C.POINTER(Stats)]
+        L.gmx_common_nbrs.argtypes = [vp, i32, i32, vp, i64, C.POINTER(i64)]
+        L.gmx_common_nbr_counts.argtypes = [vp, vp, vp, i64, vp]
+        L.gmx_triangle_counting_cn.argtypes = [vp, C.POINTER(i64), C.POINTER(Stats)]
         L.gmx_bfs_levels.argtypes = [vp, i32, vp, C.POINTER(i32)]
         L.gmx_bc.argtypes = [vp, vp, i32, C.c_int, vp, C.POINTER(Stats)]
         L.gmx_triangle_counting.argtypes = [vp, C.POINTER(i64), C.POINTER(Stats)]
@@ -334,6 +337,26 @@ class Graph:
         out = np.zeros(max(self.E, 1), np.int32)[:self.E].copy()
         _ck(lib().gmx_graph_reverse_edge_map(self._h, out.ctypes.data))
         return out
+
+    def common_nbrs(self, s, d):
+        """The items gm_common_neighbor_iter(G, s, d) yields, in order."""
+        n = C.c_int64(0)
+        _ck(lib().gmx_common_nbrs(self._h, int(s), int(d), None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.int32)
+        _ck(lib().gmx_common_nbrs(self._h, int(s), int(d), out.ctypes.data, n.value, C.byref(n)))
+        return out[:n.value]
+
+    def common_nbr_counts(self, src, dst):
+        src, dst = _i32(src), _i32(dst)
+        out = np.zeros(max(len(src), 1), np.int64)
+        _ck(lib().gmx_common_nbr_counts(self._h, src.ctypes.data, dst.ctypes.data, len(src), out.ctypes.data))
+        return out[:len(src)]
+
+    def triangle_counting_cn(self):
+        """Triangle counting written with the common-neighbour iterator -- returns (T, stats)."""
+        t, st = C.c_int64(0), Stats()
+        _ck(lib().gmx_triangle_counting_cn(self._h, C.byref(t), C.byref(st)))
+        return t.value, st.as_dict()
 
     def triangle_counting(self, part=0, nparts=1):
         """triangle_counting(G) -- returns (T, stats); with nparts > 1 the share of one part of the edge slots."""

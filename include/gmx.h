@@ -177,6 +177,18 @@ int gmx_triangle_counting(gmx_graph_t* g, int64_t* count, gmx_stats_t* stats);
  * `part` of `nparts` of the edge slots (dealt in blocks, round-robin); the parts add up to the full count. */
 int gmx_triangle_counting_part(gmx_graph_t* g, int part, int nparts, int64_t* count, gmx_stats_t* stats);
 
+/* The common-neighbour iterator, gm_common_neighbor_iter(G, s, d) (gm_common_neighbor_iter.cc:21-44): the slots of s's
+ * row, in order and with their multiplicity, whose value occurs in d's row (Foreach(u: s.CommonNbrs(d)) <=>
+ * Foreach(u: s.Nbrs)(d.isNbr(u)), gm_common_neighbor_iter.h:11-17).  gmx_common_nbrs lists them for one pair (*n = how
+ * many there are; at most cap are written), gmx_common_nbr_counts counts them for many pairs, and
+ * gmx_triangle_counting_cn is triangle counting written with the iterator
+ *   Foreach(v: G.Nodes) Foreach(u: v.Nbrs)(u > v) Foreach(w: v.CommonNbrs(u))(w > u) T += 1;
+ * (equal to gmx_triangle_counting on a symmetric graph; on a directed one it asks for u -> w where the emitted
+ * triangle_counting.gm asks for w -> u). */
+int gmx_common_nbrs(gmx_graph_t* g, gmx_node_t s, gmx_node_t d, gmx_node_t* out, int64_t cap, int64_t* n);
+int gmx_common_nbr_counts(gmx_graph_t* g, const gmx_node_t* src, const gmx_node_t* dst, int64_t npairs, int64_t* counts);
+int gmx_triangle_counting_cn(gmx_graph_t* g, int64_t* count, gmx_stats_t* stats);
+
 /* ---- device-resident PageRank stepping (bench.py / multi-GPU driver) ----
  * A gmx_pr_t owns the rows [row_lo,row_hi) of the (internally relabelled) graph
  * and a full replica of the contribution vector.  One step = one PageRank

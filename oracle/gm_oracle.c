@@ -522,6 +522,69 @@ void gmo_hop_dist(gmo_node_t numNodes,
 }
 
 /* ------------------------------------------------------------------ */
+/* gm_common_neighbor_iter (gm_common_neighbor_iter.cc:3-44): the       */
+/* iterator behind `Foreach(u: s.CommonNbrs(d))`                        */
+/* (src/backend_cpp/gm_cpp_opt_common_nbr.cc:11-26 rewrites             */
+/* `Foreach(t: x.Nbrs){ If (t.IsNbrFrom(y)) ..}` into it).  reset():    */
+/* both cursors at the row starts, finished if either row is empty;     */
+/* get_next(): take the next slot of s's row, advance d's cursor while  */
+/* it points below the value, report the value if d's cursor stops ON   */
+/* it; once either cursor runs off its row the iterator is finished     */
+/* (after the current value has been judged).  Rows are semi-sorted.    */
+/* Returns how many items it yields; the first `cap` go to out.         */
+/* ------------------------------------------------------------------ */
+int64_t gmo_common_nbrs(const gmo_edge_t* begin, const gmo_node_t* node_idx,
+                        gmo_node_t src, gmo_node_t dest, gmo_node_t* out, int64_t cap) {
+    gmo_edge_t src_idx = begin[src], src_end = begin[src + 1];
+    gmo_edge_t dest_idx = begin[dest], dest_end = begin[dest + 1];
+    int finished = (src_idx == src_end) || (dest_idx == dest_end);
+    int64_t n = 0;
+    while (!finished) {                                  /* get_next() */
+        gmo_node_t t = node_idx[src_idx];
+        src_idx++;
+        if (src_idx == src_end) finished = 1;
+        int common = 0;                                  /* check_common(t) */
+        for (;;) {
+            gmo_node_t r = node_idx[dest_idx];
+            if (r == t) { common = 1; break; }
+            if (r > t) break;
+            dest_idx++;
+            if (dest_idx == dest_end) { finished = 1; break; }
+        }
+        if (common) {
+            if (n < cap) out[n] = t;
+            n++;
+        }
+    }
+    return n;
+}
+
+/* Triangle counting written with the iterator:                         */
+/*   Foreach(v: G.Nodes) Foreach(u: v.Nbrs)(u > v)                      */
+/*     Foreach(w: v.CommonNbrs(u))(w > u) T += 1;                       */
+/* emitted as  gm_common_neighbor_iter w_I(G, v, u);                    */
+/*   for (node_t w = w_I.get_next(); w != gm_graph::NIL_NODE; w = ...)  */
+int64_t gmo_triangle_counting_cn(gmo_node_t N, const gmo_edge_t* begin, const gmo_node_t* node_idx, int nthreads) {
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    int64_t T = 0;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 128) reduction(+ : T)
+    for (gmo_node_t v = 0; v < N; v++) {
+        gmo_edge_t cap = begin[v + 1] - begin[v];
+        gmo_node_t* buf = (gmo_node_t*) malloc(sizeof(gmo_node_t) * (size_t) (cap > 0 ? cap : 1));
+        for (gmo_edge_t u_idx = begin[v]; u_idx < begin[v + 1]; u_idx++) {
+            gmo_node_t u = node_idx[u_idx];
+            if (u > v) {
+                int64_t n = gmo_common_nbrs(begin, node_idx, v, u, buf, cap);
+                for (int64_t i = 0; i < n; i++)
+                    if (buf[i] > u) T = T + 1;
+            }
+        }
+        free(buf);
+    }
+    return T;
+}
+
+/* ------------------------------------------------------------------ */
 /* comp_BC (betweenness centrality estimate over a seed sequence)      */
 /*   source apps/src/bc.gm:4-31.  `InBFS(v: G.Nodes From s)` becomes a   */
 /*   subclass of gm_bfs_template<short, omp, false, false, true>        */

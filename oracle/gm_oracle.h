@@ -107,6 +107,11 @@ void gmo_hop_dist(gmo_node_t N,
 
 /* Independent second statement of the same result: plain queue BFS.
  * Used only to cross-check gmo_hop_dist. */
+/* gm_common_neighbor_iter(G, src, dest): number of items, the first cap in out; triangle counting written with it */
+int64_t gmo_common_nbrs(const gmo_edge_t* begin, const gmo_node_t* node_idx,
+                        gmo_node_t src, gmo_node_t dest, gmo_node_t* out, int64_t cap);
+int64_t gmo_triangle_counting_cn(gmo_node_t N, const gmo_edge_t* begin, const gmo_node_t* node_idx, int nthreads);
+
 /* comp_BC of apps/src/bc.gm (skip_root: upstream's `(v != s)` filters) */
 void gmo_bc(gmo_node_t N, const gmo_edge_t* begin, const gmo_node_t* node_idx,
             const gmo_edge_t* r_begin, const gmo_node_t* r_node_idx,

@@ -50,6 +50,11 @@ def ref_lib():
     R.ref_rmat_csr.argtypes = [C.c_int32, C.c_int32, C.c_long, C.c_double, C.c_double, C.c_double, C.c_int, i32p, i32p]
     R.ref_prepare.argtypes = [C.c_int32, C.c_int32, i32p, i32p, i32p, i32p, i32p]
     R.ref_store_binary.argtypes = [C.c_char_p, C.c_int32, C.c_int32, i32p, i32p]
+    i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+    R.ref_common_nbrs.argtypes = [C.c_int32, C.c_int32, i32p, i32p, C.c_int32, i32p, i32p, i64p, i32p, C.c_int64]
+    R.ref_common_nbrs.restype = C.c_int64
+    R.ref_triangle_counting_cn.argtypes = [C.c_int32, C.c_int32, i32p, i32p]
+    R.ref_triangle_counting_cn.restype = C.c_int64
     R.ref_bc.argtypes = [C.c_int32, C.c_int32, i32p, i32p, i32p, C.c_int32, C.c_int, np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.c_int]
     R.ref_load_adj.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), i32p, i32p, C.c_int32, C.c_int32]
     R.ref_load_binary.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
@@ -167,6 +172,33 @@ def check_counts(R, name, g, salt):
         assert np.float32(c_r).tobytes() == np.float32(c_o).tobytes(), (name, "conduct", num, c_r, c_o)
         cs.append(float(np.float32(c_r)))
     return out, avgs, cs
+
+
+def check_common_nbrs(R, name, g, salt, tc=True):
+    """gm_common_neighbor_iter: the oracle restatement against the compiled reference class, item for item, on edge
+    pairs (s, d = a neighbour of s), reversed pairs and random pairs; and triangle counting written with it."""
+    rng = np.random.default_rng(1000 + salt)
+    if g.N == 0:
+        return None
+    rows = np.repeat(np.arange(g.N, dtype=np.int32), np.diff(g.begin))
+    pick = rng.integers(0, max(g.M, 1), 200) if g.M else np.zeros(0, np.int64)
+    src = np.concatenate([rows[pick], g.node_idx[pick], rng.integers(0, g.N, 100).astype(np.int32)]).astype(np.int32)
+    dst = np.concatenate([g.node_idx[pick], rows[pick], rng.integers(0, g.N, 100).astype(np.int32)]).astype(np.int32)
+    counts = np.zeros(len(src), np.int64)
+    cap = int(np.diff(g.begin)[src].sum()) + 1
+    items = np.zeros(cap, np.int32)
+    total = R.ref_common_nbrs(g.N, g.M, g.begin, g.node_idx, len(src), src, dst, counts, items, cap)
+    assert total <= cap
+    at = 0
+    for i in range(len(src)):
+        got = po.common_nbrs(g, src[i], dst[i])
+        assert len(got) == counts[i] and np.array_equal(got, items[at:at + counts[i]]), (name, "common_nbrs", int(src[i]), int(dst[i]))
+        at += int(counts[i])
+    T = None
+    if tc:
+        T = int(R.ref_triangle_counting_cn(g.N, g.M, g.begin, g.node_idx))
+        assert po.triangle_counting_cn(g) == T, (name, "tc_cn")
+    return {"cn_src": src, "cn_dst": dst, "cn_counts": counts, "tc_cn": T}
 
 
 def bc_seeds(N, root):
@@ -343,6 +375,7 @@ def main():
         assert np.array_equal(out_o, out_r), (name, "is_neighbor")
 
         bcs = check_bc(R, name, g, root) if scale <= 14 else None
+        cn = check_common_nbrs(R, name, g, scale * 2 + perm, tc=scale <= 14)
         entry = {"N": N, "M": M, "seed": 1997, "abc": [0.57, 0.19, 0.19], "permute": perm, "attempts": att,
                  "root": root, "pr_iters": it, "tc_directed": T, "tc_symmetrized": Ts, "M_sym": gs.M,
                  "reached": int((dist != INT_MAX).sum()), "max_level": int(dist[dist != INT_MAX].max()),
@@ -354,6 +387,8 @@ def main():
                  "sssp_salt": scale * 2 + perm, "sha_sssp_len": sha(sssp_len), "sha_sssp_dist": sha(sssp_dist),
                  "sssp_reached": int((sssp_dist != INT_MAX).sum()), "sssp_max": int(sssp_dist[sssp_dist != INT_MAX].max()),
                  "rank_sum": float(rank.sum()), "rank_head": [float(x) for x in rank[:4]]}
+        entry.update({"tc_cn": cn["tc_cn"], "sha_cn_src": sha(cn["cn_src"]), "sha_cn_dst": sha(cn["cn_dst"]), "sha_cn_counts": sha(cn["cn_counts"]),
+                      "cn_salt": scale * 2 + perm})
         if bcs is not None:
             entry.update({"bc_seeds": [int(x) for x in bcs["bc_seeds"]], "sha_bc": sha(bcs["bc"]), "sha_bc_skip_root": sha(bcs["bc_skip_root"]),
                           "bc_nan": int(np.isnan(bcs["bc"]).sum()), "bc_skip_root_nan": int(np.isnan(bcs["bc_skip_root"]).sum()),
@@ -362,7 +397,8 @@ def main():
         if scale <= 10:   # small enough to commit in full
             fixtures[name] = dict(begin=begin, raw_node_idx=raw, node_idx=snode, r_begin=rb, r_node_idx=rn,
                                   rank=rank, rank20=rank20, dist=dist, sssp_len=sssp_len, sssp_dist=sssp_dist,
-                                  age=props["age"], member=props["member"], teen_cnt=props["teen_cnt"], **bc_arrays(bcs))
+                                  age=props["age"], member=props["member"], teen_cnt=props["teen_cnt"],
+                                  cn_src=cn["cn_src"], cn_dst=cn["cn_dst"], cn_counts=cn["cn_counts"], **bc_arrays(bcs))
         print("%s: pinned (iters=%d, reached=%d, T=%s, Tsym=%s)" % (name, it, entry["reached"], T, Ts))
 
     # ---- 3. hand graphs ----
@@ -398,10 +434,13 @@ def main():
         sssp_len, sssp_dist = check_sssp(R, name, g, root, len(name))
         props, teen_avgs, conducts = check_counts(R, name, g, len(name))
         bcs = check_bc(R, name, g, root)
+        cn = check_common_nbrs(R, name, g, len(name)) if len(edges) else None
         fixtures["hand_" + name] = dict(begin=begin, raw_node_idx=raw, node_idx=g.node_idx, r_begin=g.r_begin,
                                         r_node_idx=g.r_node_idx, rank=rank, dist=dist, sssp_len=sssp_len, sssp_dist=sssp_dist,
                                         age=props["age"], member=props["member"], teen_cnt=props["teen_cnt"], **bc_arrays(bcs))
-        manifest["hand"][name] = {"N": N, "M": len(edges), "root": root, "pr_iters": it, "tc": T,
+        if cn is not None:
+            fixtures["hand_" + name].update(cn_src=cn["cn_src"], cn_dst=cn["cn_dst"], cn_counts=cn["cn_counts"])
+        manifest["hand"][name] = {"N": N, "M": len(edges), "root": root, "pr_iters": it, "tc": T, "tc_cn": cn["tc_cn"] if cn else 0,
                                   "teen_avg_K5_K25_K100": teen_avgs, "conduct_0_4": conducts}
         print("hand %s: pinned (iters=%d T=%d)" % (name, it, T))
 

@@ -52,6 +52,10 @@ def lib():
         L.gmo_avg_teen_cnt.restype = C.c_float
         L.gmo_conduct.argtypes = [C.c_int32, i32p, i32p, i32p, C.c_int32, C.c_int]
         L.gmo_conduct.restype = C.c_float
+        L.gmo_common_nbrs.argtypes = [i32p, i32p, C.c_int32, C.c_int32, i32p, C.c_int64]
+        L.gmo_common_nbrs.restype = C.c_int64
+        L.gmo_triangle_counting_cn.argtypes = [C.c_int32, i32p, i32p, C.c_int]
+        L.gmo_triangle_counting_cn.restype = C.c_int64
         L.gmo_bc.argtypes = [C.c_int32, i32p, i32p, i32p, i32p, i32p, C.c_int32, C.c_int, f32p]
         L.gmo_bc.restype = None
         L.gmo_bfs_queue.argtypes = [C.c_int32, i32p, i32p, C.c_int32, i32p]
@@ -188,6 +192,18 @@ def conduct(g, member, num, nthreads=0):
     """conduct(G, member, num) -> float32."""
     member = np.ascontiguousarray(member, np.int32)
     return np.float32(lib().gmo_conduct(g.N, g.begin, g.node_idx, member, int(num), nthreads))
+
+
+def common_nbrs(g, s, d):
+    """Items of gm_common_neighbor_iter(G, s, d), in order."""
+    cap = int(g.begin[s + 1] - g.begin[s])
+    out = np.zeros(max(cap, 1), np.int32)
+    n = lib().gmo_common_nbrs(g.begin, g.node_idx, int(s), int(d), out, cap)
+    return out[:n]
+
+
+def triangle_counting_cn(g, nthreads=0):
+    return int(lib().gmo_triangle_counting_cn(g.N, g.begin, g.node_idx, nthreads))
 
 
 def bc(g, seeds, skip_root=False):

@@ -22,6 +22,7 @@
 #include <math.h>
 
 #include "gm.h"          // reference umbrella header (apps/output_cpp/gm_graph/inc/gm.h)
+#include "gm_common_neighbor_iter.h"
 #include "graph_gen.h"   // create_RMAT_graph
 
 extern "C" {
@@ -431,6 +432,46 @@ int ref_bfs_levels(int32_t N, int32_t M, const int32_t* begin, const int32_t* no
     }
     delete gp;
     return 0;
+}
+
+/* ---- the reference's gm_common_neighbor_iter (gm_common_neighbor_iter.cc), as is ---- */
+int64_t ref_common_nbrs(int32_t N, int32_t M, const int32_t* begin, const int32_t* node_idx, int32_t n_pairs,
+                        const int32_t* src, const int32_t* dst, int64_t* counts, int32_t* items, int64_t cap) {
+    gm_graph* gp = make_graph(N, M, begin, node_idx);
+    gp->do_semi_sort();
+    int64_t total = 0;
+    for (int32_t i = 0; i < n_pairs; i++) {
+        gm_common_neighbor_iter it(*gp, src[i], dst[i]);
+        int64_t c = 0;
+        for (node_t w = it.get_next(); w != gm_graph::NIL_NODE; w = it.get_next()) {
+            if (total < cap) items[total] = w;
+            total++;
+            c++;
+        }
+        counts[i] = c;
+    }
+    delete gp;
+    return total;
+}
+
+/* triangle counting through that iterator (emitted form of Foreach(w: v.CommonNbrs(u))(w > u)) */
+int64_t ref_triangle_counting_cn(int32_t N, int32_t M, const int32_t* begin, const int32_t* node_idx) {
+    gm_graph* gp = make_graph(N, M, begin, node_idx);
+    gm_graph& G = *gp;
+    G.freeze();
+    G.do_semi_sort();
+    int64_t T = 0;
+    for (node_t v = 0; v < G.num_nodes(); v++)
+        for (edge_t u_idx = G.begin[v]; u_idx < G.begin[v + 1]; u_idx++) {
+            node_t u = G.node_idx[u_idx];
+            if (u > v) {
+                gm_common_neighbor_iter w_I(G, v, u);
+                for (node_t w = w_I.get_next(); w != gm_graph::NIL_NODE; w = w_I.get_next())
+                    if (w > u) T = T + 1;
+            }
+        }
+    delete gp;
+    return T;
 }
 
 /* ---- comp_BC (apps/src/bc.gm): the traversal, the level bookkeeping, is_down_edge and the forward / reverse

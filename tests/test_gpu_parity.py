@@ -142,6 +142,31 @@ def same_f32(a, b):
     return np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32))
 
 
+def test_common_neighbour_iterator_and_tc_cn(gmx, golden):
+    """gmx_common_nbrs / gmx_common_nbr_counts = gm_common_neighbor_iter (items in order, multiplicity of the first
+    row; fixtures pinned against the compiled reference class) and triangle counting written with it."""
+    for name, c, m in host_graphs(golden):
+        if "cn_src" not in c:
+            continue
+        g = gmx.Graph.upload(c["begin"], c["node_idx"], c["r_begin"], c["r_node_idx"])
+        og = po.Graph(m["N"], c["begin"].copy(), c["node_idx"].copy(), c["r_begin"].copy(), c["r_node_idx"].copy())
+        assert np.array_equal(g.common_nbr_counts(c["cn_src"], c["cn_dst"]), c["cn_counts"]), name
+        for s, d in list(zip(c["cn_src"], c["cn_dst"]))[:60]:
+            assert np.array_equal(g.common_nbrs(s, d), po.common_nbrs(og, s, d)), (name, int(s), int(d))
+        if m.get("tc_cn") is not None:
+            assert g.triangle_counting_cn()[0] == m["tc_cn"], name
+        g.free()
+    for scale, permute in ((14, True), (16, False)):
+        og = po.rmat_graph(scale, permute=permute)
+        g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+        assert g.triangle_counting_cn()[0] == po.triangle_counting_cn(og)
+        gs = g.symmetrize()
+        T, _ = gs.triangle_counting()
+        assert gs.triangle_counting_cn()[0] == T                      # the LDS-staged oriented kernel serves both forms
+        gs.free()
+        g.free()
+
+
 def test_bfs_object_levels_and_bc_golden(gmx, golden):
     """The device BFS object (gm_bfs_template's role for InBFS / InReverse): levels as the template keeps them
     (short, unvisited -2; the fixtures' dist[] equals gm_bfs_template<short,...> levels, oracle/make_golden.py),

@@ -44,6 +44,20 @@ def same_f32(a, b):
     return np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32))
 
 
+def check_common_nbrs(g, c, m):
+    """gm_common_neighbor_iter: counts on the fixture's pairs (pinned item for item against the compiled reference
+    class when the fixtures were made), and triangle counting written with the iterator."""
+    if "cn_src" in c:
+        got = [len(po.common_nbrs(g, s, d)) for s, d in zip(c["cn_src"], c["cn_dst"])]
+        assert got == c["cn_counts"].tolist()
+        for s, d in list(zip(c["cn_src"], c["cn_dst"]))[:40]:        # the definition: Foreach(u: s.Nbrs)(d.isNbr(u))
+            row_s = g.node_idx[g.begin[s]:g.begin[s + 1]]
+            row_d = g.node_idx[g.begin[d]:g.begin[d + 1]]
+            assert np.array_equal(po.common_nbrs(g, s, d), row_s[np.isin(row_s, row_d)])
+    if m.get("tc_cn") is not None:
+        assert po.triangle_counting_cn(g) == m["tc_cn"]
+
+
 def check_bc(g, c):
     """comp_BC (bc.gm): this fork's form and upstream's, against the reference-pinned arrays."""
     assert same_f32(po.bc(g, c["bc_seeds"], False), c["bc"])
@@ -73,6 +87,7 @@ def test_rmat_fixture_full(golden, name):
     assert sha(c["sssp_len"]) == m["sha_sssp_len"] and sha(c["sssp_dist"]) == m["sha_sssp_dist"]
     check_counts(g, c, m)
     check_bc(g, c)
+    check_common_nbrs(g, c, m)
     assert po.triangle_counting(g) == m["tc_directed"]
     assert po.triangle_counting_merge(g) == m["tc_directed"]
     gs = po.symmetrize(g)
@@ -103,7 +118,12 @@ def test_rmat_fixture_hashed(golden, name):
             assert sha(got) == m["sha_" + key] and int(np.isnan(got).sum()) == m[key + "_nan"]
     if m["tc_directed"] is not None:
         assert po.triangle_counting_merge(g) == m["tc_directed"]
-    assert po.triangle_counting_merge(po.symmetrize(g)) == m["tc_symmetrized"]
+    if m.get("tc_cn") is not None:
+        assert po.triangle_counting_cn(g) == m["tc_cn"]
+    gsym = po.symmetrize(g)
+    assert po.triangle_counting_merge(gsym) == m["tc_symmetrized"]
+    if m["N"] <= (1 << 14):
+        assert po.triangle_counting_cn(gsym) == m["tc_symmetrized"]     # symmetric graph: both forms count triangles
 
 
 def test_hand_graphs(golden):
@@ -119,6 +139,7 @@ def test_hand_graphs(golden):
         assert np.array_equal(po.sssp(g, c["sssp_len"], m["root"])[0], c["sssp_dist"]), name
         check_counts(g, c, m)
         check_bc(g, c)
+        check_common_nbrs(g, c, m)
         assert po.triangle_counting(g) == m["tc"], name
         assert po.triangle_counting_merge(g) == m["tc"], name
 
