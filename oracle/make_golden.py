@@ -55,6 +55,9 @@ def ref_lib():
     R.ref_common_nbrs.restype = C.c_int64
     R.ref_triangle_counting_cn.argtypes = [C.c_int32, C.c_int32, i32p, i32p]
     R.ref_triangle_counting_cn.restype = C.c_int64
+    R.ref_uniform_graph.argtypes = [C.c_int32, C.c_int32, C.c_long, C.c_int, i32p, i32p]
+    R.ref_rand32_min.argtypes = [C.c_long, C.c_int32]
+    R.ref_rand32_min.restype = C.c_int32
     R.ref_bc.argtypes = [C.c_int32, C.c_int32, i32p, i32p, i32p, C.c_int32, C.c_int, np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.c_int]
     R.ref_load_adj.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), i32p, i32p, C.c_int32, C.c_int32]
     R.ref_load_binary.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
@@ -443,6 +446,21 @@ def main():
         manifest["hand"][name] = {"N": N, "M": len(edges), "root": root, "pr_iters": it, "tc": T, "tc_cn": cn["tc_cn"] if cn else 0,
                                   "teen_avg_K5_K25_K100": teen_avgs, "conduct_0_4": conducts}
         print("hand %s: pinned (iters=%d T=%d)" % (name, it, T))
+
+    # ---- 3b. the uniform generators (graph_gen.cc:12-105): outputs of the compiled reference, for the host
+    #          library's create_uniform_random_graph_new (tests/test_host_cpp.py compares)
+    manifest["uniform"] = {}
+    for nm, (N, M, seed, xs) in {"uniform_rand_1000_8000": (1000, 8000, 1997, 0), "uniform_rand_77_2000": (77, 2000, 5, 0),
+                                 "uniform_xorshift_1000_8000": (1000, 8000, 1997, 1)}.items():
+        if xs and R.ref_rand32_min(seed, 2 * M) < 0:
+            print("%s: skipped -- the reference's xorshift stream goes negative (r %% N would index out of bounds)" % nm)
+            manifest["uniform"][nm] = {"N": N, "M": M, "seed": seed, "xorshift": xs, "skipped": "negative draws: undefined behaviour in the reference"}
+            continue
+        ub, un = np.zeros(N + 1, np.int32), np.zeros(M, np.int32)
+        assert R.ref_uniform_graph(N, M, seed, xs, ub, un) == 0
+        fixtures[nm] = dict(begin=ub, node_idx=un)
+        manifest["uniform"][nm] = {"N": N, "M": M, "seed": seed, "xorshift": xs, "sha_begin": sha(ub), "sha_node_idx": sha(un)}
+        print("%s: pinned" % nm)
 
     # ---- 4. binary format ----
     begin, raw, snode, rb, rn = ref_graph(R, 256, 4096, 1997, 0.57, 0.19, 0.19, False)

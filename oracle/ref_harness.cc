@@ -23,6 +23,7 @@
 
 #include "gm.h"          // reference umbrella header (apps/output_cpp/gm_graph/inc/gm.h)
 #include "gm_common_neighbor_iter.h"
+#include "gm_rand.h"
 #include "graph_gen.h"   // create_RMAT_graph
 
 extern "C" {
@@ -432,6 +433,26 @@ int ref_bfs_levels(int32_t N, int32_t M, const int32_t* begin, const int32_t* no
     }
     delete gp;
     return 0;
+}
+
+/* ---- the reference's uniform generator (graph_gen.cc:12-55), as is: rows as it leaves them (unsorted) ----
+ * (the xorshift mode is only safe while gm_rand32 stays non-negative: `r % N` of a negative draw indexes
+ * degree[] out of bounds, graph_gen.cc:27-35; the caller checks that with ref_rand32_min first) */
+int ref_uniform_graph(int32_t N, int32_t M, long seed, int use_xorshift, int32_t* begin, int32_t* node_idx) {
+    gm_graph G;
+    create_uniform_random_graph_new(G, N, M, seed, use_xorshift != 0);
+    memcpy(begin, G.begin, sizeof(int32_t) * ((size_t) N + 1));
+    memcpy(node_idx, G.node_idx, sizeof(int32_t) * (size_t) M);
+    return 0;
+}
+int32_t ref_rand32_min(long seed, int32_t n) {
+    gm_rand r(seed);
+    int32_t mn = 0x7fffffff;
+    for (int32_t i = 0; i < n; i++) {
+        int32_t v = (int32_t) r.rand();
+        if (v < mn) mn = v;
+    }
+    return mn;
 }
 
 /* ---- the reference's gm_common_neighbor_iter (gm_common_neighbor_iter.cc), as is ---- */

@@ -22,8 +22,10 @@ def golden():
     import numpy as np
     z = np.load(os.path.join(GOLD, "golden.npz"), allow_pickle=False)
     man = json.load(open(os.path.join(GOLD, "manifest.json")))
-    cases = {}
+    cases, other = {}, {}
     for k in z.files:
         name, field = k.split("/")
-        cases.setdefault(name, {})[field] = z[k]
-    return {"cases": cases, "manifest": man}
+        # "cases": graphs with the full set of reference-pinned results; "uniform": outputs of the reference's
+        # uniform generator only
+        (other if name.startswith("uniform_") else cases).setdefault(name, {})[field] = z[k]
+    return {"cases": cases, "uniform": other, "manifest": man}

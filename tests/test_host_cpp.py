@@ -144,6 +144,24 @@ def test_driver_rmat_input(host_built, golden):
     assert got == [float("%0.9f" % x) for x in m["rank_head"]]
 
 
+def test_uniform_generators_match_reference(host_built, golden, tmp_path):
+    """create_uniform_random_graph_new / create_uniform_random_graph (graph_gen.cc:12-105: glibc rand() or the
+    xorshift stream, rows filled from their last slot backwards) against the arrays the compiled reference wrote."""
+    exe = str(tmp_path / "uniform_check")
+    subprocess.check_call(["g++"] + CXX_FLAGS + [os.path.join(ROOT, "tests", "cpp", "uniform_check.cc"), "-o", exe] + LINK)
+    n = 0
+    for name, m in golden["manifest"]["uniform"].items():
+        if "skipped" in m:
+            continue
+        dump = str(tmp_path / (name + ".txt"))
+        subprocess.check_call([exe, str(m["N"]), str(m["M"]), str(m["seed"]), str(m["xorshift"]), dump])
+        d = parse_dump(dump)
+        c = golden["uniform"][name]
+        assert np.array_equal(d["begin"], c["begin"]) and np.array_equal(d["node_idx"], c["node_idx"]), name
+        n += 1
+    assert n >= 2
+
+
 def _unsorted_check(tmp_path, gpu):
     exe = str(tmp_path / "unsorted_check")
     subprocess.check_call(["g++"] + CXX_FLAGS + [os.path.join(ROOT, "tests", "cpp", "unsorted_check.cc"), "-o", exe] + LINK)
