@@ -26,10 +26,36 @@
 
 #define BFS_THREADS 256
 
+// Statistics that thousands of waves add to (edges inspected, vertices found by a bottom-up level) are spread over
+// BFS_SHARDS cache lines and summed by the host after the read-back: atomics on ONE line retire at ~90 per
+// microsecond device-wide, and two such adds per wave were 0.37 ms of a 0.39 ms bottom-up level at RMAT-20 (and
+// ~0.7 ms per bottom-up level at RMAT-26).  Both run on: a level's count is the difference to the previous total.
+#define BFS_SHARDS 64
 struct bfs_counters {
-    unsigned long long next_count;     // vertices discovered in this level
-    unsigned long long edges;          // edges inspected so far
+    unsigned long long next_count;     // top-down: tail of the next queue = vertices discovered in this level
+    unsigned long long next_edges;     // their out-edges: the next level's merge-path length and the input of the
+                                       // direction decision, known without a pass over the new queue
+    unsigned long long pad0[14];
+    struct {
+        unsigned long long edges;      // edges inspected so far
+        unsigned long long found;      // vertices found by bottom-up levels so far
+        unsigned long long pad[14];
+    } shard[BFS_SHARDS];
 };
+__device__ __forceinline__ void bfs_count(bfs_counters* __restrict__ ctr, unsigned long long edges, unsigned long long found) {
+    const int sh = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (BFS_SHARDS - 1);
+    if (edges) atomicAdd(&ctr->shard[sh].edges, edges);
+    if (found) atomicAdd(&ctr->shard[sh].found, found);
+}
+static void bfs_totals(const bfs_counters& h, unsigned long long* edges, unsigned long long* found) {
+    unsigned long long e = 0, f = 0;
+    for (int i = 0; i < BFS_SHARDS; i++) {
+        e += h.shard[i].edges;
+        f += h.shard[i].found;
+    }
+    *edges = e;
+    *found = f;
+}
 
 __global__ void bfs_init_kernel(int32_t* __restrict__ dist, int64_t V, int32_t root) {
     int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -38,7 +64,8 @@ __global__ void bfs_init_kernel(int32_t* __restrict__ dist, int64_t V, int32_t r
 }
 
 __device__ __forceinline__ void bfs_visit(int32_t s, int32_t next_level, int32_t* __restrict__ dist,
-                                          int32_t* __restrict__ next_q, bfs_counters* __restrict__ ctr) {
+                                          int32_t* __restrict__ next_q, bfs_counters* __restrict__ ctr,
+                                          const int32_t* __restrict__ begin) {
     // <s.dist_nxt; s.updated_nxt> min= <n.dist + 1; True>   (hop_dist.gm:21)
     bool won = false;
     if (dist[s] == INT_MAX) won = (atomicMin(&dist[s], next_level) == INT_MAX);
@@ -46,8 +73,14 @@ __device__ __forceinline__ void bfs_visit(int32_t s, int32_t next_level, int32_t
     if (m) {
         int lane = threadIdx.x & 63;
         int leader = __ffsll((long long) m) - 1;
+        unsigned long long deg = won ? (unsigned long long) (begin[s + 1] - begin[s]) : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) deg += __shfl_xor(deg, o, 64);
         unsigned long long base = 0;
-        if (lane == leader) base = atomicAdd(&ctr->next_count, (unsigned long long) __popcll(m));
+        if (lane == leader) {
+            base = atomicAdd(&ctr->next_count, (unsigned long long) __popcll(m));
+            if (deg) atomicAdd(&ctr->next_edges, deg);
+        }
         base = __shfl(base, leader, 64);
         if (won) next_q[base + __popcll(m & ((1ULL << lane) - 1))] = s;
     }
@@ -62,6 +95,52 @@ __global__ void bfs_degree_kernel(const int32_t* __restrict__ begin, const int32
     for (; i < n; i += stride) {
         int32_t v = q[i];
         deg[i] = begin[v + 1] - begin[v];
+    }
+}
+
+// A small frontier (n <= BFS_SMALL_SCAN): degrees and their exclusive prefix sums off[0..n] in ONE launch of one
+// workgroup -- the library scan is two launches behind a degree kernel, and with the two read-backs per level that
+// made a level of a small graph cost ~150 us of launches and round trips.  Also clears the counters of the level
+// that is about to run (saves a memset).
+#define BFS_SMALL_SCAN 16384
+#define BFS_SMALL_PER (BFS_SMALL_SCAN / 1024)
+__global__ void __launch_bounds__(1024)
+bfs_degree_scan_small_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ q, int n,
+                             int64_t* __restrict__ off, bfs_counters* __restrict__ ctr) {
+    __shared__ long long s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    long long d[BFS_SMALL_PER], sum = 0;
+#pragma unroll
+    for (int j = 0; j < BFS_SMALL_PER; j++) {
+        const int i = tid * BFS_SMALL_PER + j;
+        d[j] = 0;
+        if (i < n) {
+            const int32_t v = q[i];
+            d[j] = begin[v + 1] - begin[v];
+        }
+        sum += d[j];
+    }
+    long long incl = sum;   // inclusive scan of the threads' sums: inside the wave, then over the 16 waves
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    long long wbase = 0;
+    for (int w = 0; w < wv; w++) wbase += s_wave[w];
+    long long run = wbase + incl - sum;
+#pragma unroll
+    for (int j = 0; j < BFS_SMALL_PER; j++) {
+        const int i = tid * BFS_SMALL_PER + j;
+        if (i < n) off[i] = run;
+        run += d[j];
+        if (i == n - 1) off[n] = run;
+    }
+    if (tid == 0) {
+        ctr->next_count = 0;
+        ctr->next_edges = 0;
     }
 }
 
@@ -107,11 +186,11 @@ bfs_topdown_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict_
         }
         int32_t s = node_idx[(int64_t) s_row[lo] + (x - s_off[lo])];
         inspected++;
-        bfs_visit(s, level + 1, dist, next_q, ctr);
+        bfs_visit(s, level + 1, dist, next_q, ctr, begin);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) inspected += __shfl_down(inspected, o, 64);
-    if ((tid & 63) == 0 && inspected) atomicAdd(&ctr->edges, inspected);
+    if ((tid & 63) == 0) bfs_count(ctr, inspected, 0);
 }
 
 // frontier bitmap of a level straight from dist[] (coalesced reads, one __ballot per 64 vertices, no atomics)
@@ -206,6 +285,8 @@ struct gmx_bfs {
     dbuf<unsigned long long> qcount;
     int32_t level = 0;
     int64_t cur_count = 0, reached = 0, explored = 0;
+    unsigned long long found_total = 0;   // bottom-up finds so far (the device counter runs on)
+    int64_t cur_edges = -1;           // out-edges of the current queue when the level that built it counted them, else -1
     unsigned long long edges = 0;
     bool frontier_is_bitmap = false, frontier_bm_valid = false, pending_bottom_up = false;
     int32_t* cur_q = nullptr;
@@ -220,6 +301,7 @@ struct gmx_bfs {
     }
 };
 
+#define BFS_BU_OWN 32   // in-row entries a vertex checks alone before its wave helps
 // owned vertices [v_lo, v_hi), v_lo a multiple of 64: one found word per wave, no atomics
 __global__ void __launch_bounds__(BFS_THREADS)
 bfs_bottomup_part_kernel(const int32_t* __restrict__ r_begin, const int32_t* __restrict__ r_node_idx,
@@ -229,11 +311,18 @@ bfs_bottomup_part_kernel(const int32_t* __restrict__ r_begin, const int32_t* __r
     int64_t t = v_lo + (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
     unsigned long long inspected = 0, found_cnt = 0;
+    const int lane = threadIdx.x & 63;
     for (; t < v_hi; t += stride) {   // v_hi - v_lo is a multiple of 64: whole waves
+        // A vertex looks for a parent among the first BFS_BU_OWN entries of its in-row by itself (most rows are
+        // shorter, and most long ones find a parent at once); what is left of the long rows is then searched by the
+        // whole wave, one row at a time, 64 entries per step with an early exit -- a lone lane walking a
+        // 10^4-entry row of a vertex that has no parent in this level was the tail of the whole level.
         bool found = false;
+        int32_t rest_b = 0, rest_e = 0;
         if (t < V && dist[t] == INT_MAX) {
             const int32_t b = r_begin[t], e = r_begin[t + 1];
-            for (int32_t i = b; i < e; i++) {
+            const int32_t own_e = e - b > BFS_BU_OWN ? b + BFS_BU_OWN : e;
+            for (int32_t i = b; i < own_e; i++) {
                 const int32_t w = r_node_idx[i];
                 inspected++;
                 if (frontier_bm[w >> 5] & (1u << (w & 31))) {
@@ -241,6 +330,28 @@ bfs_bottomup_part_kernel(const int32_t* __restrict__ r_begin, const int32_t* __r
                     break;
                 }
             }
+            if (!found && own_e < e) {
+                rest_b = own_e;
+                rest_e = e;
+            }
+        }
+        unsigned long long pending = __ballot(rest_e > rest_b);
+        while (pending) {
+            const int src = __ffsll((long long) pending) - 1;
+            pending &= pending - 1;
+            const int32_t rb = __shfl(rest_b, src, 64), re = __shfl(rest_e, src, 64);
+            bool hit = false;
+            for (int32_t i0 = rb; i0 < re && !hit; i0 += 64) {
+                const int32_t i = i0 + lane;
+                bool mine = false;
+                if (i < re) {
+                    const int32_t w = r_node_idx[i];
+                    inspected++;
+                    mine = (frontier_bm[w >> 5] & (1u << (w & 31))) != 0;
+                }
+                hit = __ballot(mine) != 0ull;
+            }
+            if (lane == src) found = hit;
         }
         const unsigned long long m = __ballot(found);
         if ((threadIdx.x & 63) == 0) found_bm[t >> 6] = m;
@@ -253,10 +364,7 @@ bfs_bottomup_part_kernel(const int32_t* __restrict__ r_begin, const int32_t* __r
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) inspected += __shfl_down(inspected, off, 64);
-    if ((threadIdx.x & 63) == 0) {
-        if (inspected) atomicAdd(&ctr->edges, inspected);
-        if (found_cnt) atomicAdd(&ctr->next_count, found_cnt);
-    }
+    if ((threadIdx.x & 63) == 0) bfs_count(ctr, inspected, found_cnt);
 }
 
 // every rank, whole bitmap: dist[v] = next_level where the bit is set; counts the new frontier
@@ -271,7 +379,7 @@ __global__ void bfs_apply_found_kernel(const unsigned long long* __restrict__ fo
         if (v < V && ((m >> (v & 63)) & 1ULL)) dist[v] = next_level;
         if ((threadIdx.x & 63) == 0) cnt += (unsigned long long) __popcll(m);
     }
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&ctr->next_count, cnt);
+    if ((threadIdx.x & 63) == 0) bfs_count(ctr, 0, cnt);
 }
 
 extern "C" int gmx_bfs_create(gmx_graph_t* g, int rank, int nranks, gmx_bfs_t** out) {
@@ -334,7 +442,14 @@ extern "C" int gmx_bfs_start(gmx_bfs_t* b, gmx_node_t root) {
     b->fr = 0;
     b->cur_q = b->q0.p;
     b->next_q = b->q1.p;
-    if (root_ok) GMX_HIP(hipMemcpy(b->q0.p, &root, sizeof(int32_t), hipMemcpyHostToDevice));
+    b->cur_edges = -1;
+    b->found_total = 0;
+    if (root_ok) {
+        GMX_HIP(hipMemcpy(b->q0.p, &root, sizeof(int32_t), hipMemcpyHostToDevice));
+        int32_t rb[2] = {0, 0};
+        GMX_HIP(hipMemcpy(rb, b->g->begin.p + root, 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+        b->cur_edges = rb[1] - rb[0];
+    }
     GMX_HIP(hipDeviceSynchronize());
     return GMX_OK;
 }
@@ -358,16 +473,20 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
     if (b->cur_count <= 0) return GMX_OK;
     gmx_graph* g = b->g;
     const int64_t V = b->V;
-    GMX_HIP(hipMemsetAsync(&b->ctr.p->next_count, 0, sizeof(unsigned long long), 0));   // `edges` keeps accumulating
     int64_t m_f = 0;
-    bool bottom_up;
+    bool bottom_up, have_off = false, cleared = false;
     if (b->frontier_is_bitmap) bottom_up = b->cur_count > V / 24;
     else {
-        GMX_CHECK(bfs_frontier_edges(b, &m_f));
+        if (b->cur_edges >= 0) m_f = b->cur_edges;   // counted by the level that built the queue: no pass, no read-back
+        else {
+            GMX_CHECK(bfs_frontier_edges(b, &m_f));
+            have_off = true;
+        }
         bottom_up = g->has_reverse && (b->cur_count > V / 20 || m_f > (g->E - b->explored) / 14);
         b->explored += m_f;
     }
     if (bottom_up) {
+        GMX_HIP(hipMemsetAsync(&b->ctr.p->next_count, 0, 2 * sizeof(unsigned long long), 0));   // next_count, next_edges; `edges` keeps accumulating
         if (!b->frontier_bm_valid)   // first bottom-up level after queue levels: frontier = {v : dist[v] == level}
             hipLaunchKernelGGL(bfs_level_bitmap_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
                                (const int32_t*) b->dist.p, V, b->level, b->bm[b->fr].p);
@@ -389,9 +508,23 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
                                    (const int32_t*) b->dist.p, V, b->level, b->cur_q, b->qcount.p);
             b->frontier_is_bitmap = false;
             GMX_CHECK(bfs_frontier_edges(b, &m_f));
+            have_off = true;
             b->explored += m_f;
         }
         b->frontier_bm_valid = false;
+        if (!have_off) {   // merge-path offsets of the queue
+            if (b->cur_count <= BFS_SMALL_SCAN) {
+                hipLaunchKernelGGL(bfs_degree_scan_small_kernel, dim3(1), dim3(1024), 0, 0, g->begin.p, (const int32_t*) b->cur_q,
+                                   (int) b->cur_count, b->off.p, b->ctr.p);
+                cleared = true;
+            } else {
+                hipLaunchKernelGGL(bfs_degree_kernel, dim3(grid_for(b->cur_count)), dim3(BFS_THREADS), 0, 0, g->begin.p, b->cur_q, b->cur_count, b->deg.p);
+                size_t tb = b->scan_bytes;
+                GMX_HIP(rocprim::inclusive_scan(b->scan_tmp.p, tb, b->deg.p, b->off.p + 1, (size_t) b->cur_count, rocprim::plus<int64_t>(), 0));
+                GMX_HIP(hipMemsetAsync(b->off.p, 0, sizeof(int64_t), 0));
+            }
+        }
+        if (!cleared) GMX_HIP(hipMemsetAsync(&b->ctr.p->next_count, 0, 2 * sizeof(unsigned long long), 0));
         const int64_t nb = (b->cur_count + m_f + BFS_ITEMS - 1) / BFS_ITEMS;
         if (nb > 0)
             hipLaunchKernelGGL(bfs_topdown_kernel, dim3((unsigned) nb), dim3(BFS_THREADS), 0, 0,
@@ -400,6 +533,7 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
         b->cur_q = b->next_q;
         b->next_q = t;
     }
+    b->cur_edges = bottom_up ? -1 : -2;   // -2: a top-down level is running, step_end learns the next queue's edges
     GMX_HIP(hipGetLastError());
     return GMX_OK;
 }
@@ -429,9 +563,14 @@ extern "C" int gmx_bfs_step_end(gmx_bfs_t* b, int64_t* next_count) {
     }
     GMX_HIP(hipMemcpyAsync(b->h_ctr, b->ctr.p, sizeof(bfs_counters), hipMemcpyDeviceToHost, 0));
     GMX_HIP(hipStreamSynchronize(0));
-    const bfs_counters h = *b->h_ctr;
-    b->cur_count = (int64_t) h.next_count;
-    b->edges = h.edges;
+    const bfs_counters& h = *b->h_ctr;
+    unsigned long long edges = 0, found = 0;
+    bfs_totals(h, &edges, &found);
+    // a top-down level leaves its queue tail in next_count, a bottom-up level its finds in the running total
+    b->cur_count = b->cur_edges == -2 ? (int64_t) h.next_count : (int64_t) (found - b->found_total);
+    b->found_total = found;
+    b->cur_edges = b->cur_edges == -2 ? (int64_t) h.next_edges : -1;
+    b->edges = edges;
     b->reached += b->cur_count;
     b->level++;
     *next_count = b->cur_count;
@@ -563,7 +702,7 @@ sssp_relax_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) inspected += __shfl_down(inspected, o, 64);
-    if ((tid & 63) == 0 && inspected) atomicAdd(&ctr->edges, inspected);
+    if ((tid & 63) == 0) bfs_count(ctr, inspected, 0);
 }
 
 __global__ void sssp_init_kernel(int32_t* __restrict__ dist, int32_t* __restrict__ stamp, int64_t V, int32_t root) {
@@ -669,9 +808,10 @@ extern "C" int gmx_sssp(gmx_graph_t* g, gmx_node_t root, const int32_t* len_host
         GMX_HIP(hipGetLastError());
         GMX_HIP(hipMemcpyAsync(h_ctr, ctr.p, sizeof(bfs_counters), hipMemcpyDeviceToHost, 0));
         GMX_HIP(hipStreamSynchronize(0));
-        const bfs_counters h = *h_ctr;
+        const bfs_counters& h = *h_ctr;
+        unsigned long long found_unused = 0;
         cur_count = (int64_t) h.next_count;
-        edges = h.edges;
+        bfs_totals(h, &edges, &found_unused);
         requeued += cur_count;
         int32_t* t = cur_q;
         cur_q = next_q;
