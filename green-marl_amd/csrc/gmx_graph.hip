@@ -219,24 +219,36 @@ int gmx_csr_from_keys(uint64_t* keys, uint64_t* keys_alt, int64_t V, int64_t E,
 }
 
 // Build forward (and reverse) CSR of g from device keys (row<<32|col), consuming them.
-static int build_from_forward_keys(gmx_graph* g, dbuf<uint64_t>& keys, dbuf<uint64_t>& alt, bool want_reverse, bool keep_order = false) {
+// sorted_csr (optional): the uploaded CSR the keys were made from; when its rows turn out to be in order already it
+// becomes the forward CSR as it is (no sort, identity e_idx2idx)
+static int build_from_forward_keys(gmx_graph* g, dbuf<uint64_t>& keys, dbuf<uint64_t>& alt, bool want_reverse, bool keep_order = false,
+                                   dbuf<int32_t>* up_begin = nullptr, dbuf<int32_t>* up_idx = nullptr) {
     hipStream_t s = 0;
-    GMX_CHECK(g->begin.alloc((size_t) g->V + 1));
-    GMX_CHECK(g->node_idx.alloc((size_t) g->E));
     int32_t* slots = nullptr;
-    if (keep_order && g->E > 1) {   // rows out of order: remember where every sorted slot came from (e_idx2idx)
+    bool in_order = false;
+    if ((keep_order || (up_begin && up_idx)) && g->E > 1) {   // rows out of order + keep_order: remember where every sorted slot came from (e_idx2idx)
         dbuf<int> flag;
         GMX_CHECK(flag.alloc(1));
         GMX_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), s));
         hipLaunchKernelGGL(rows_unsorted_kernel, dim3(grid_for(g->E)), dim3(256), 0, s, (const uint64_t*) keys.p, g->E, flag.p);
         int h = 0;
         GMX_HIP(hipMemcpy(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost));
-        if (h) {
+        if (h && keep_order) {
             GMX_CHECK(g->e_idx2idx.alloc((size_t) g->E));
             slots = g->e_idx2idx.p;
         }
+        in_order = !h && up_begin && up_idx;
     }
-    GMX_CHECK(gmx_csr_from_keys(keys.p, alt.p, g->V, g->E, g->begin.p, g->node_idx.p, s, slots));
+    if (in_order) {   // (what a file written after a semi-sort looks like)
+        g->begin.p = up_begin->take();
+        g->begin.n = (size_t) g->V + 1;
+        g->node_idx.p = up_idx->take();
+        g->node_idx.n = (size_t) g->E;
+    } else {
+        GMX_CHECK(g->begin.alloc((size_t) g->V + 1));
+        GMX_CHECK(g->node_idx.alloc((size_t) g->E));
+        GMX_CHECK(gmx_csr_from_keys(keys.p, alt.p, g->V, g->E, g->begin.p, g->node_idx.p, s, slots));
+    }
     if (want_reverse) {
         GMX_CHECK(g->r_begin.alloc((size_t) g->V + 1));
         GMX_CHECK(g->r_node_idx.alloc((size_t) g->E));
@@ -283,7 +295,7 @@ extern "C" int gmx_graph_upload(const gmx_edge_t* begin, const gmx_node_t* node_
                 break;
             }
             if ((st = gmx_keys_from_csr(tb.p, ti.p, V, E, false, nullptr, keys.p, 0))) break;
-            if ((st = build_from_forward_keys(g, keys, alt, want_rev, (flags & GMX_GRAPH_SORT_ROWS) != 0))) break;
+            if ((st = build_from_forward_keys(g, keys, alt, want_rev, (flags & GMX_GRAPH_SORT_ROWS) != 0, &tb, &ti))) break;
         } else {
             if ((st = g->begin.alloc((size_t) V + 1)) || (st = g->node_idx.alloc((size_t) E))) break;
             if (hipMemcpy(g->begin.p, begin, sizeof(int32_t) * ((size_t) V + 1), hipMemcpyHostToDevice) != hipSuccess ||
