@@ -131,6 +131,12 @@ struct pr_cold_fuse {
 // enqueue phases 1-3: reads the contribution replica; fuse == NULL leaves the row sums in pr_cold_partial(),
 // otherwise the rows are finished in place and pr_cold_diff_partials() holds the |val - rank| partials
 int pr_cold_launch(pr_cold* c, const void* contrib, const pr_cold_fuse* fuse, hipStream_t s);
+// the same in pieces (see pr_cold_set_parts in gmx_pr_cold.hip): phase 1 per tile class, phases 2-3 per row part
+int pr_cold_set_parts(pr_cold* c, int nparts, const int64_t* act_bound, int64_t hub, int64_t live);
+int pr_cold_parts(const pr_cold* c);
+int64_t pr_cold_class_items(const pr_cold* c, int cls);   // phase-1 work items of a tile class
+int pr_cold_gather(pr_cold* c, const void* contrib, int cls, hipStream_t s);
+int pr_cold_accumulate(pr_cold* c, const pr_cold_fuse* fuse, int part, hipStream_t s);
 const double* pr_cold_diff_partials(const pr_cold* c, int64_t* n);
 bool pr_cold_covers_all_rows(const pr_cold* c);
 const void* pr_cold_partial(const pr_cold* c);   // [nactive] x elem, indexed like the per-slice partial sums

@@ -125,8 +125,11 @@ struct gmx_pr {
     // process, one copy stream per peer
     int step_next = 1;                       // replica the running step writes
     std::vector<char*> peer_buf[2];          // [nranks] base of rank r's contrib[b]; own entry unused
-    std::vector<hipStream_t> push_stream;    // [nranks]
-    std::vector<hipEvent_t> push_done;       // [nranks]
+    // two sets of copy streams: the chunks of a step alternate between them, so the small hub piece (sent last, needed
+    // first by the peers' next step) does not queue behind the long tail piece
+    std::vector<hipStream_t> push_stream[2]; // [nranks]
+    std::vector<hipEvent_t> push_done[2];    // [nranks]
+    int gather_mask = 0;                     // tile classes whose phase 1 has been enqueued for the running step (binned, fused form)
     hipEvent_t push_ready = nullptr;         // "this chunk is computed", recorded on the step's stream
     double* h_diff = nullptr;                // pinned landing place of gmx_pr_diff
     // dominant-kernel timing (hipEvents on the launch stream)
@@ -135,13 +138,15 @@ struct gmx_pr {
     int ev_used = 0;
     ~gmx_pr() {
         for (hipEvent_t e : ev) (void) hipEventDestroy(e);
-        for (hipStream_t st : push_stream)
-            if (st) {
-                (void) hipStreamSynchronize(st);
-                (void) hipStreamDestroy(st);
-            }
-        for (hipEvent_t e : push_done)
-            if (e) (void) hipEventDestroy(e);
+        for (int q = 0; q < 2; q++) {
+            for (hipStream_t st : push_stream[q])
+                if (st) {
+                    (void) hipStreamSynchronize(st);
+                    (void) hipStreamDestroy(st);
+                }
+            for (hipEvent_t e : push_done[q])
+                if (e) (void) hipEventDestroy(e);
+        }
         if (push_ready) (void) hipEventDestroy(push_ready);
         if (h_diff) (void) hipHostFree(h_diff);
         pr_cold_free(cold);
@@ -1117,6 +1122,8 @@ __global__ void pr_unpermute_kernel(int64_t rows, const int32_t* __restrict__ in
 
 // ------------------------------------------------------------------ plan
 static int pr_build_chunks(gmx_pr* p, int C);
+// every in-edge of the owned rows is binned and every row is reached by the bins' fused finish
+static inline bool pr_fused(const gmx_pr* p) { return p->cold && p->Eh == 0 && pr_cold_covers_all_rows(p->cold); }
 
 extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nranks, uint32_t options, gmx_pr_t** out) {
     GMX_REQUIRE(out, "out is NULL");
@@ -1453,6 +1460,7 @@ extern "C" int gmx_pr_reset(gmx_pr_t* p, double d) {
     p->d = d;
     p->cnt = 0;
     p->cur = 0;
+    p->gather_mask = 0;
     if (p->rows > 0) {
         if (p->elem == 4)
             hipLaunchKernelGGL(pr_reset_kernel<float>, dim3(grid_for(p->rows)), dim3(256), 0, 0, p->rows, (double) p->V,
@@ -1537,6 +1545,8 @@ static int pr_build_chunks(gmx_pr* p, int C) {
         for (int q = 0; q < p->ns; q++) p->ch_blk[j][q] = (j == C) ? p->sl.s[q].nblk : (j == 0 ? 0 : h[(size_t) j * (p->ns + 1) + q]);
         p->ch_act[j] = (j == C) ? p->sl_nactive : (j == 0 ? 0 : h[(size_t) j * (p->ns + 1) + p->ns]);
     }
+    if (pr_fused(p))   // the binned phases in the same pieces: bins by row chunk, tiles by "hub sources only"
+        GMX_CHECK(pr_cold_set_parts(p->cold, C, p->ch_act, C > 1 ? pr_chunk_bound(p, 1) : p->exchange_count, p->exchange_count));
     if (getenv("GMX_PR_DEBUG"))
         for (int j = 0; j <= C; j++) {
             fprintf(stderr, "gmx pr chunk %d: row %lld active %lld blocks", j, (long long) p->ch_row[j], (long long) p->ch_act[j]);
@@ -1558,22 +1568,29 @@ static void launch_sliced_chunk(gmx_pr* p, int c, hipStream_t s) {
     const int j = C - 1 - c;
     S* next_owned = (S*) p->contrib[1 - p->cur].p + p->row_lo;
     pr_sliced_args a = p->sl;
-    if (p->cold && p->Eh == 0 && C == 1 && pr_cold_covers_all_rows(p->cold)) {
-        // every edge is binned and the step is one piece: the binned phases finish the rows themselves (no
-        // partial-sum array, no combine pass)
+    if (pr_fused(p)) {
+        // every edge is binned: the binned phases finish the rows themselves (no partial-sum array, no combine pass).
+        // Phase 1 (unless gmx_pr_step_gather has enqueued it already), then phases 2-3 of this chunk's bins.
         const pr_cold_fuse fz{(const int32_t*) p->sl_active.p, (const int32_t*) p->sl_outdeg_c.p, (void*) p->sl_rk_c.p, (void*) next_owned, base, p->d};
-        (void) pr_cold_launch(p->cold, p->contrib[p->cur].p, &fz, s);
+        if (c == 0) {
+            for (int k = 0; k < 2; k++)
+                if (!(p->gather_mask & (1 << k))) (void) pr_cold_gather(p->cold, p->contrib[p->cur].p, k, s);
+        }
         double* dfirst = p->diff_part.p + PR_COMBINE_GRID;
-        if (p->cnt == 0) {   // first sweep after a reset: settle the rows without in-edges once
+        if (c == 0 && p->cnt == 0) {   // first sweep after a reset: settle the rows without in-edges once (all chunks' rows)
             hipLaunchKernelGGL(pr_inactive_first_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, (const uint8_t*) p->sl_is_active.p,
                                (int64_t) 0, p->rows, p->outdeg.p, (S*) p->rk.p, next_owned, base, p->d, dfirst);
             hipLaunchKernelGGL(pr_inactive_copy_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, (const uint8_t*) p->sl_is_active.p,
                                p->rows, (S*) p->contrib[p->cur].p + p->row_lo, (const S*) next_owned);
         }
-        int64_t nd = 0;
-        const double* dp = pr_cold_diff_partials(p->cold, &nd);
-        hipLaunchKernelGGL(pr_diff_reduce2_kernel, dim3(1), dim3(1024), 0, s, dp, nd, (const double*) dfirst,
-                           (int64_t) (p->cnt == 0 ? PR_COMBINE_GRID : 0), p->diff.p);
+        if (pr_cold_parts(p->cold) == C) (void) pr_cold_accumulate(p->cold, &fz, c, s);
+        else if (c == 0) (void) pr_cold_accumulate(p->cold, &fz, -1, s);
+        if (c == C - 1) {
+            int64_t nd = 0;
+            const double* dp = pr_cold_diff_partials(p->cold, &nd);
+            hipLaunchKernelGGL(pr_diff_reduce2_kernel, dim3(1), dim3(1024), 0, s, dp, nd, (const double*) dfirst,
+                               (int64_t) (p->cnt == 0 ? PR_COMBINE_GRID : 0), p->diff.p);
+        }
         return;
     }
     // the binned sources' row sums of ALL rows, once per step, before the first chunk is combined
@@ -1683,11 +1700,43 @@ extern "C" int gmx_pr_chunk_range(gmx_pr_t* p, int chunk, int64_t* offset, int64
     return GMX_OK;
 }
 
+extern "C" int gmx_pr_gather_classes(gmx_pr_t* p, int* classes) {
+    GMX_REQUIRE(p && classes, "NULL argument");
+    *classes = pr_fused(p) ? 2 : 0;
+    return GMX_OK;
+}
+
+extern "C" int gmx_pr_gather_items(gmx_pr_t* p, int tile_class, int64_t* items) {
+    GMX_REQUIRE(p && items, "NULL argument");
+    *items = pr_fused(p) ? pr_cold_class_items(p->cold, tile_class) : 0;
+    return GMX_OK;
+}
+
+// Binned, fused form only (gmx_pr_gather_classes > 0): enqueue phase 1 -- the only part of a step that reads the
+// other ranks' contributions -- for one tile class ahead of gmx_pr_step_chunk(0).  Class 0: tiles all of whose live
+// sources lie in the hub piece of a rank range (chunk_range of the LAST chunk), i.e. what the peers send last and
+// what arrives first; class 1: the rest.  Class 0 opens the step.
+extern "C" int gmx_pr_step_gather(gmx_pr_t* p, int cls, void* stream) {
+    GMX_REQUIRE(p, "pr is NULL");
+    GMX_REQUIRE(pr_fused(p), "gmx_pr_step_gather needs a plan with every edge binned (gmx_pr_gather_classes)");
+    GMX_REQUIRE(cls == 0 || cls == 1, "tile class %d out of range", cls);
+    GMX_REQUIRE(!(p->gather_mask & (1 << cls)) && (cls == 0 || (p->gather_mask & 1)), "tile classes are enqueued once per step, 0 before 1");
+    hipStream_t s = (hipStream_t) stream;
+    if (cls == 0) {
+        pr_ev_begin(p, s);
+        p->step_next = 1 - p->cur;
+    }
+    if (p->rows > 0) GMX_CHECK(pr_cold_gather(p->cold, p->contrib[p->cur].p, cls, s));
+    p->gather_mask |= 1 << cls;
+    GMX_HIP(hipGetLastError());
+    return GMX_OK;
+}
+
 extern "C" int gmx_pr_step_chunk(gmx_pr_t* p, int chunk, void* stream) {
     GMX_REQUIRE(p, "pr is NULL");
     GMX_REQUIRE(chunk >= 0 && chunk < p->nchunks, "chunk %d out of range", chunk);
     hipStream_t s = (hipStream_t) stream;
-    if (chunk == 0) {
+    if (chunk == 0 && !(p->gather_mask & 1)) {
         pr_ev_begin(p, s);   // one "launch" of the roofline = all kernels of one step
         p->step_next = 1 - p->cur;
     }
@@ -1706,6 +1755,7 @@ extern "C" int gmx_pr_step_chunk(gmx_pr_t* p, int chunk, void* stream) {
         }
     }
     GMX_HIP(hipGetLastError());
+    if (chunk == 0) p->gather_mask = 0;
     if (chunk == p->nchunks - 1) {
         pr_ev_end(p, s);
         p->cur = 1 - p->cur;
@@ -1768,13 +1818,15 @@ extern "C" int gmx_pr_set_peers(gmx_pr_t* p, void* const* peer_buf0, void* const
     GMX_REQUIRE(p && peer_buf0 && peer_buf1, "NULL argument");
     for (int r = 0; r < p->nranks; r++)
         if (r != p->rank) GMX_REQUIRE(peer_buf0[r] && peer_buf1[r], "peer %d: NULL replica pointer", r);
-    if (p->push_stream.empty()) {
-        p->push_stream.assign((size_t) p->nranks, nullptr);
-        p->push_done.assign((size_t) p->nranks, nullptr);
-        for (int r = 0; r < p->nranks; r++) {
-            if (r == p->rank) continue;
-            GMX_HIP(hipStreamCreateWithFlags(&p->push_stream[r], hipStreamNonBlocking));
-            GMX_HIP(hipEventCreateWithFlags(&p->push_done[r], hipEventDisableTiming));
+    if (p->push_stream[0].empty()) {
+        for (int q = 0; q < 2; q++) {
+            p->push_stream[q].assign((size_t) p->nranks, nullptr);
+            p->push_done[q].assign((size_t) p->nranks, nullptr);
+            for (int r = 0; r < p->nranks; r++) {
+                if (r == p->rank) continue;
+                GMX_HIP(hipStreamCreateWithFlags(&p->push_stream[q][r], hipStreamNonBlocking));
+                GMX_HIP(hipEventCreateWithFlags(&p->push_done[q][r], hipEventDisableTiming));
+            }
         }
         GMX_HIP(hipEventCreateWithFlags(&p->push_ready, hipEventDisableTiming));
     }
@@ -1784,7 +1836,7 @@ extern "C" int gmx_pr_set_peers(gmx_pr_t* p, void* const* peer_buf0, void* const
 }
 
 // entries [offset, offset+count) of this rank's range, from replica b to the same place in every peer's replica b
-static int pr_push_range(gmx_pr* p, int b, int64_t offset, int64_t count, hipStream_t s) {
+static int pr_push_range(gmx_pr* p, int b, int64_t offset, int64_t count, hipStream_t s, int set = 0) {
     if (p->nranks == 1) return GMX_OK;
     GMX_REQUIRE(!p->peer_buf[0].empty(), "gmx_pr_set_peers has not been called");
     GMX_REQUIRE(offset >= 0 && count >= 0 && offset + count <= p->slice, "push range outside the rank's range");
@@ -1793,8 +1845,8 @@ static int pr_push_range(gmx_pr* p, int b, int64_t offset, int64_t count, hipStr
     const size_t at = (size_t) (p->row_lo + offset) * p->elem, bytes = (size_t) count * p->elem;
     for (int i = 1; i < p->nranks; i++) {
         const int r = (p->rank + i) % p->nranks;   // every rank starts with a different peer
-        GMX_HIP(hipStreamWaitEvent(p->push_stream[r], p->push_ready, 0));
-        GMX_HIP(hipMemcpyAsync(p->peer_buf[b][r] + at, p->contrib[b].p + at, bytes, hipMemcpyDeviceToDevice, p->push_stream[r]));
+        GMX_HIP(hipStreamWaitEvent(p->push_stream[set][r], p->push_ready, 0));
+        GMX_HIP(hipMemcpyAsync(p->peer_buf[b][r] + at, p->contrib[b].p + at, bytes, hipMemcpyDeviceToDevice, p->push_stream[set][r]));
     }
     return GMX_OK;
 }
@@ -1803,7 +1855,7 @@ extern "C" int gmx_pr_push_chunk(gmx_pr_t* p, int chunk, void* stream) {
     GMX_REQUIRE(p, "pr is NULL");
     int64_t off = 0, cnt = 0;
     GMX_CHECK(gmx_pr_chunk_range(p, chunk, &off, &cnt));
-    return pr_push_range(p, p->step_next, off, cnt, (hipStream_t) stream);
+    return pr_push_range(p, p->step_next, off, cnt, (hipStream_t) stream, chunk & 1);
 }
 
 extern "C" int gmx_pr_push_current(gmx_pr_t* p, void* stream) {
@@ -1811,14 +1863,26 @@ extern "C" int gmx_pr_push_current(gmx_pr_t* p, void* stream) {
     return pr_push_range(p, p->cur, 0, p->exchange_count, (hipStream_t) stream);
 }
 
-extern "C" int gmx_pr_push_join(gmx_pr_t* p, void* stream) {
-    GMX_REQUIRE(p, "pr is NULL");
-    for (int r = 0; r < (int) p->push_stream.size(); r++) {
-        if (!p->push_stream[r]) continue;
-        GMX_HIP(hipEventRecord(p->push_done[r], p->push_stream[r]));
-        GMX_HIP(hipStreamWaitEvent((hipStream_t) stream, p->push_done[r], 0));
+static int pr_push_join_set(gmx_pr* p, int set, hipStream_t stream) {
+    for (int r = 0; r < (int) p->push_stream[set].size(); r++) {
+        if (!p->push_stream[set][r]) continue;
+        GMX_HIP(hipEventRecord(p->push_done[set][r], p->push_stream[set][r]));
+        GMX_HIP(hipStreamWaitEvent(stream, p->push_done[set][r], 0));
     }
     return GMX_OK;
+}
+
+extern "C" int gmx_pr_push_join(gmx_pr_t* p, void* stream) {
+    GMX_REQUIRE(p, "pr is NULL");
+    GMX_CHECK(pr_push_join_set(p, 0, (hipStream_t) stream));
+    return pr_push_join_set(p, 1, (hipStream_t) stream);
+}
+
+// `stream` waits for the copies of ONE chunk (and whatever was queued before them on the same copy streams)
+extern "C" int gmx_pr_push_join_chunk(gmx_pr_t* p, int chunk, void* stream) {
+    GMX_REQUIRE(p, "pr is NULL");
+    GMX_REQUIRE(chunk >= 0 && chunk < p->nchunks, "chunk %d out of range", chunk);
+    return pr_push_join_set(p, chunk & 1, (hipStream_t) stream);
 }
 
 extern "C" int gmx_pr_contrib_slice(gmx_pr_t* p, void** dev_ptr, int64_t* count) {

@@ -86,6 +86,15 @@ struct pr_cold {
     dbuf<prc_item2> it2;
     dbuf<prc_item3> it3;
     int64_t n1p = 0, n1e = 0, n2 = 0, n3 = 0, nslots = 0;
+    // The step can be cut into parts (pr_cold_set_parts): phase 1 by tile CLASS (0: every live source of the tile lies
+    // in the hub piece of its rank range, 1: the rest), phases 2-3 by row part (bins), in processing order.
+    std::vector<prc_item1> h1p, h1e;    // host copies of the work lists, in the order they were made
+    std::vector<prc_item2> h2;
+    std::vector<prc_item3> h3;
+    int nparts = 1;
+    int64_t o1[3] = {0, 0, 0};          // it1p: items [o1[k], o1[k + 1]) belong to tile class k
+    std::vector<int64_t> o2, o3, o3few; // it2 / it3: items [o[c], o[c + 1]) belong to part c; the first o3few[c] of a part's it3 items have few slots
+    uint32_t q1 = 0, q2 = 0;            // what the work counters of phase 1 / 2 hold before the next launch
     dbuf<unsigned long long> scratch;   // [nslots][limbs][binrows]
     dbuf<unsigned int> queue;           // [3 * 64]
     dbuf<double> diffp;                 // fused finish: [n2] partials of phase 2, then [n3 * binrows / 64] of phase 3
@@ -307,7 +316,7 @@ __device__ __forceinline__ void prc_load_tile(S* __restrict__ s_tile, int tile, 
         const int64_t left = span - l;
         const int n = left < TILE - 1 - i0 ? (int) left : TILE - 1 - i0;
         const S* __restrict__ src = contrib + ((int64_t) r * slice + T + l);
-#pragma unroll 8
+#pragma unroll 16
         for (int j = threadIdx.x; j < n; j += PRC_THREADS) s_tile[i0 + j] = __builtin_nontemporal_load(src + j);
         i0 += n;
         r++;
@@ -580,7 +589,8 @@ template <typename S, int TILE>
 __global__ void __launch_bounds__(PRC_THREADS)
 pr_cold_tile_kernel(const prc_item1* __restrict__ items, int n_items, unsigned int* __restrict__ queue,
                     const S* __restrict__ contrib, const int32_t* __restrict__ org, int nranks, int64_t span, int64_t slice, int64_t T,
-                    const uint16_t* __restrict__ srcl, const int32_t* __restrict__ ob, S* __restrict__ val, unsigned sink_base) {
+                    const uint16_t* __restrict__ srcl, const int32_t* __restrict__ ob, S* __restrict__ val, unsigned sink_base,
+                    unsigned qbase) {
     __shared__ S s_tile[TILE];
     __shared__ S s_stage[PRC_WAVES][PRC_STAGE_BYTES / sizeof(S) + 64];   // + a dummy slot per lane
     __shared__ int s_item;
@@ -590,7 +600,7 @@ pr_cold_tile_kernel(const prc_item1* __restrict__ items, int n_items, unsigned i
     int loaded = -1;
     for (;;) {
         __syncthreads();   // everybody is done with s_item and the tile of the previous item
-        if (tid == 0) s_item = (int) atomicAdd(&queue[PRC_Q1P], 1u);
+        if (tid == 0) s_item = (int) (atomicAdd(&queue[PRC_Q1P], 1u) - qbase);
         __syncthreads();
         const int it = s_item;
         if (it >= n_items) break;
@@ -643,7 +653,7 @@ __global__ void __launch_bounds__(PRC_THREADS)
 pr_cold_accum_kernel(const prc_item2* __restrict__ items, int n_items, unsigned int* __restrict__ queue,
                      const uint16_t* __restrict__ rowl, const S* __restrict__ val, int64_t nactive, double lo_scale,
                      S* __restrict__ cold, unsigned long long* __restrict__ scratch, pr_cold_fuse fz,
-                     double* __restrict__ diff_part) {
+                     double* __restrict__ diff_part, unsigned qbase) {
     typedef typename prc_vec4<S>::type V4;
     __shared__ unsigned long long s_acc[LIMBS * BINROWS];
     __shared__ double s_red[PRC_WAVES];
@@ -652,7 +662,7 @@ pr_cold_accum_kernel(const prc_item2* __restrict__ items, int n_items, unsigned 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (;;) {
         __syncthreads();   // the previous item has been flushed
-        if (tid == 0) s_item = (int) atomicAdd(&queue[PRC_Q2], 1u);
+        if (tid == 0) s_item = (int) (atomicAdd(&queue[PRC_Q2], 1u) - qbase);
 #pragma unroll 4
         for (int i = tid; i < LIMBS * BINROWS; i += PRC_THREADS) s_acc[i] = 0ull;
         __syncthreads();
@@ -765,6 +775,126 @@ pr_cold_reduce_kernel(const prc_item3* __restrict__ items, int64_t nactive, doub
         }
     }
 }
+
+// The same for bins split into a few chunks only (small partitions: most bins are cut in two or three): a wave takes
+// 64 rows and walks the slots itself -- no idle waves, no LDS round.
+#define PRC_FEW_SLOTS 8
+template <typename S, int BINROWS, int LIMBS, bool FUSE>
+__global__ void __launch_bounds__(256)
+pr_cold_reduce_few_kernel(const prc_item3* __restrict__ items, int64_t nactive, double lo_scale,
+                          const unsigned long long* __restrict__ scratch, S* __restrict__ cold, pr_cold_fuse fz,
+                          double* __restrict__ diff_part) {
+    const prc_item3 d = items[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int rg = blockIdx.x * 4 + (threadIdx.x >> 6);   // group of 64 rows
+    const int r = rg * 64 + lane;
+    const int64_t i0 = (int64_t) d.bin * BINROWS;
+    unsigned long long hi = 0, lo = 0;
+    const unsigned long long* src = scratch + (int64_t) d.slot0 * (LIMBS * BINROWS) + r;
+#pragma unroll 4
+    for (int s = 0; s < d.nslots; s++) {
+        hi += __builtin_nontemporal_load(src + (int64_t) s * (LIMBS * BINROWS));
+        if (LIMBS > 1) lo += __builtin_nontemporal_load(src + (int64_t) s * (LIMBS * BINROWS) + BINROWS);
+    }
+    double diff_acc = 0.0;
+    if (i0 + r < nactive) {
+        double v = (double) (long long) hi * 0x1p-62;
+        if (LIMBS > 1) v += (double) (long long) lo * (0x1p-62 / lo_scale);
+        if (FUSE) prc_finish_row<S>(fz, i0 + r, v, diff_acc);
+        else cold[i0 + r] = (S) v;
+    }
+    if (FUSE) {   // the 64 rows' |val - rank| in lane order, like the many-slot kernel
+        double t = 0.0;
+        for (int l = 0; l < 64; l++) t += __shfl(diff_acc, l, 64);
+        if (lane == 0) diff_part[(int64_t) blockIdx.y * (BINROWS / 64) + rg] = t;
+    }
+}
+
+// ------------------------------------------------------------------ work lists
+// (Re)build the device work lists from the host copies: phase 1 grouped by tile class, phases 2-3 by part; inside a
+// group the big items come first (the queue then balances the tail with small ones), pair items before edge items,
+// few-slot reductions before many-slot ones.
+static int prc_upload_lists(pr_cold* c, const std::vector<uint8_t>* tile_class, const std::vector<int32_t>* bin_part, int nparts) {
+    auto by_size1 = [](const prc_item1& a, const prc_item1& b) { return a.g1 - a.g0 > b.g1 - b.g0; };
+    auto by_size2 = [](const prc_item2& a, const prc_item2& b) { return a.g1 - a.g0 > b.g1 - b.g0; };
+    std::vector<prc_item1> l1;
+    for (int k = 0; k < 2; k++) {
+        c->o1[k] = (int64_t) l1.size();
+        for (int form = 1; form >= 0; form--) {
+            std::vector<prc_item1> a;
+            for (const prc_item1& it : (form ? c->h1p : c->h1e))
+                if ((tile_class ? (int) (*tile_class)[(size_t) it.tile] : 0) == k) a.push_back(it);
+            std::stable_sort(a.begin(), a.end(), by_size1);
+            l1.insert(l1.end(), a.begin(), a.end());
+        }
+    }
+    c->o1[2] = (int64_t) l1.size();
+    std::vector<prc_item2> l2;
+    std::vector<prc_item3> l3;
+    c->o2.assign((size_t) nparts + 1, 0);
+    c->o3.assign((size_t) nparts + 1, 0);
+    c->o3few.assign((size_t) nparts, 0);
+    for (int q = 0; q < nparts; q++) {
+        c->o2[(size_t) q] = (int64_t) l2.size();
+        c->o3[(size_t) q] = (int64_t) l3.size();
+        std::vector<prc_item2> a;
+        for (const prc_item2& it : c->h2)
+            if ((bin_part ? (*bin_part)[(size_t) it.bin] : 0) == q) a.push_back(it);
+        std::stable_sort(a.begin(), a.end(), by_size2);
+        l2.insert(l2.end(), a.begin(), a.end());
+        for (int few = 1; few >= 0; few--)
+            for (const prc_item3& it : c->h3)
+                if ((bin_part ? (*bin_part)[(size_t) it.bin] : 0) == q && (it.nslots <= PRC_FEW_SLOTS ? 1 : 0) == few) {
+                    l3.push_back(it);
+                    if (few) c->o3few[(size_t) q]++;
+                }
+    }
+    c->o2[(size_t) nparts] = (int64_t) l2.size();
+    c->o3[(size_t) nparts] = (int64_t) l3.size();
+    c->nparts = nparts;
+    if ((int64_t) l1.size() != c->n1p + c->n1e || (int64_t) l2.size() != c->n2 || (int64_t) l3.size() != c->n3) {
+        gmx_set_error("pr cold: work lists lost items while being regrouped");
+        return GMX_ERR_ARG;
+    }
+    if (!l1.empty()) GMX_HIP(hipMemcpy(c->it1p.p, l1.data(), sizeof(prc_item1) * l1.size(), hipMemcpyHostToDevice));
+    if (!l2.empty()) GMX_HIP(hipMemcpy(c->it2.p, l2.data(), sizeof(prc_item2) * l2.size(), hipMemcpyHostToDevice));
+    if (!l3.empty()) GMX_HIP(hipMemcpy(c->it3.p, l3.data(), sizeof(prc_item3) * l3.size(), hipMemcpyHostToDevice));
+    return GMX_OK;
+}
+
+// Cut the step into parts.  act_bound[j] (j = 0 .. nparts, row order): position in the active-row list where row part
+// j starts; parts are numbered in PROCESSING order, which is from the last row part to the first, and the bin that
+// holds a boundary goes with the later row part (processed earlier), so every row of a part's range is finished when
+// the part is.  Tile classes: the entries [0, hub) of a rank range are its hub piece, [hub, live) the rest of what is
+// ever read; a tile is class 0 if every live source it holds lies in a hub piece.
+int pr_cold_set_parts(pr_cold* c, int nparts, const int64_t* act_bound, int64_t hub, int64_t live) {
+    if (!c || c->Ec == 0) return GMX_OK;
+    if (nparts <= 1) return prc_upload_lists(c, nullptr, nullptr, 1);
+    std::vector<int32_t> bin_part((size_t) c->nbins, 0);
+    {
+        std::vector<int64_t> bb((size_t) nparts + 1, 0);
+        for (int j = 1; j < nparts; j++) bb[(size_t) j] = std::min<int64_t>(c->nbins, act_bound[j] / c->binrows);
+        bb[(size_t) nparts] = c->nbins;
+        for (int j = 0; j < nparts; j++)
+            for (int64_t b = bb[(size_t) j]; b < bb[(size_t) j + 1]; b++) bin_part[(size_t) b] = nparts - 1 - j;
+    }
+    std::vector<uint8_t> tile_class((size_t) c->ntiles, 0);
+    const int64_t span = c->prm.slice - c->prm.T, tile_src = c->tile - 1;
+    for (int64_t t = 0; t < c->ntiles; t++) {
+        const int64_t cp0 = t * tile_src, cp1 = std::min<int64_t>(cp0 + tile_src, span * c->prm.nranks);
+        bool hub_only = true;
+        for (int64_t r = cp0 / span; r * span < cp1 && hub_only; r++) {
+            const int64_t o0 = c->prm.T + std::max<int64_t>(cp0, r * span) - r * span;          // range offsets [o0, o1)
+            const int64_t o1 = c->prm.T + std::min<int64_t>(cp1, (r + 1) * span) - r * span;
+            if (o0 < live && std::min(o1, live) > hub) hub_only = false;
+        }
+        tile_class[(size_t) t] = hub_only ? 0 : 1;
+    }
+    return prc_upload_lists(c, &tile_class, &bin_part, nparts);
+}
+
+int pr_cold_parts(const pr_cold* c) { return c ? c->nparts : 1; }
+int64_t pr_cold_class_items(const pr_cold* c, int cls) { return c && cls >= 0 && cls < 2 ? c->o1[cls + 1] - c->o1[cls] : 0; }
 
 // ------------------------------------------------------------------ plan
 #define PRC_TRY(expr, what)                                                                  \
@@ -1004,13 +1134,18 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
     }
     // ---- work lists ----
     {
-        // Work item sizes: about four items per CU (an item costs a tile copy / an accumulator flush and a few
-        // barriers: RMAT-26 fp32 runs 1.74 ms per iteration with 32 Ki-group items, 1.84 with 8 Ki, 2.06 with 2 Ki),
-        // at most 1 Mi entries; phase 2 then only splits the hub bins (every split costs 128 KiB of accumulators
-        // written and read again).
-        const int64_t want1 = ngroups1 / ((int64_t) c->grid * 4), want2 = ngroups2 / ((int64_t) c->grid * 2);
+        // Work item sizes: about four items per CU (an item costs a tile copy -- 124 KiB, as much as 2 Ki groups of
+        // entries -- an accumulator flush and a few barriers: RMAT-26 fp32 runs 1.74 ms per iteration with 32 Ki-group
+        // items, 1.84 with 8 Ki, 2.06 with 2 Ki), at most 1 Mi entries, and only two per CU when four would make them
+        // smaller than 8 Ki groups (rank 0 of an 8-rank partition of RMAT-26: 0.312 ms with 8 Ki, 0.335 with 4 Ki,
+        // 0.455 with 1 Ki); phase 2 then only splits the hub bins (every split costs 128 KiB of accumulators written
+        // and read again: a bin is cut when it exceeds three chunks).
+        const int64_t want1 = std::max<int64_t>(ngroups1 / ((int64_t) c->grid * 4), std::min<int64_t>(8192, ngroups1 / ((int64_t) c->grid * 2)));
+        const int64_t want2 = ngroups2 / ((int64_t) c->grid * 2);
         const int ch1 = (int) std::min<int64_t>(32768, std::max<int64_t>(PRC_SUPER_GROUPS, prc_env_int("GMX_PR_COLD_CHUNK1", (int) std::min<int64_t>(want1, 32768)))) / PRC_SUPER_GROUPS * PRC_SUPER_GROUPS;
         const int ch2 = (int) std::min<int64_t>(32768, std::max<int64_t>(8, prc_env_int("GMX_PR_COLD_CHUNK", (int) std::min<int64_t>(std::max<int64_t>(want2, 2048), 32768)))) / 8 * 8;
+        // a bin is split when it exceeds thr2 (a split costs its accumulators written and read again)
+        const int64_t thr2 = (int64_t) ch2 * prc_env_int("GMX_PR_COLD_SPLIT_X100", 300) / 100;
         for (int64_t t = 0; t < c->ntiles; t++) {
             const int32_t g0 = tstart[t];
             // pair tiles run whole blocks (the padding behind the last cell ends no pair); edge tiles stop at the
@@ -1023,31 +1158,27 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
         for (int64_t b = 0; b < c->nbins; b++) {
             const int32_t g0 = h2[b], g1 = h2[b + 1];
             if (g1 <= g0) { c->all_bins = false; continue; }
-            if (g1 - g0 <= ch2) { v2.push_back({(int32_t) b, g0, g1, -1}); continue; }
+            if (g1 - g0 <= thr2) { v2.push_back({(int32_t) b, g0, g1, -1}); continue; }
             const int32_t s0 = slot;
             for (int32_t g = g0; g < g1; g += ch2) v2.push_back({(int32_t) b, g, std::min(g1, g + ch2), slot++});
             v3.push_back({(int32_t) b, s0, slot - s0, 0});
         }
-        // big items first: the queue then balances the tail with small ones
-        auto by_size1 = [](const prc_item1& a, const prc_item1& b) { return a.g1 - a.g0 > b.g1 - b.g0; };
-        std::stable_sort(v1p.begin(), v1p.end(), by_size1);
-        std::stable_sort(v1e.begin(), v1e.end(), by_size1);
-        std::stable_sort(v2.begin(), v2.end(), [](const prc_item2& a, const prc_item2& b) { return a.g1 - a.g0 > b.g1 - b.g0; });
         c->n1p = (int64_t) v1p.size();
         c->n1e = (int64_t) v1e.size();
         c->n2 = (int64_t) v2.size();
         c->n3 = (int64_t) v3.size();
         c->nslots = slot;
-        v1p.insert(v1p.end(), v1e.begin(), v1e.end());   // one queue: pair items, then the edge items
-        PRC_ALLOC(c->it1p, std::max<size_t>(1, v1p.size()));
+        PRC_ALLOC(c->it1p, std::max<size_t>(1, v1p.size() + v1e.size()));
         PRC_ALLOC(c->it2, std::max<size_t>(1, v2.size()));
         PRC_ALLOC(c->it3, std::max<size_t>(1, v3.size()));
         PRC_ALLOC(c->scratch, std::max<size_t>(1, (size_t) slot * c->limbs * c->binrows));
         PRC_ALLOC(c->diffp, std::max<size_t>(1, v2.size() + v3.size() * (size_t) (c->binrows / 64)));
         PRC_TRY(hipMemset(c->diffp.p, 0, sizeof(double) * std::max<size_t>(1, v2.size() + v3.size() * (size_t) (c->binrows / 64))), "memset");
-        if (!v1p.empty()) PRC_TRY(hipMemcpy(c->it1p.p, v1p.data(), sizeof(prc_item1) * v1p.size(), hipMemcpyHostToDevice), "copy");
-        if (!v2.empty()) PRC_TRY(hipMemcpy(c->it2.p, v2.data(), sizeof(prc_item2) * v2.size(), hipMemcpyHostToDevice), "copy");
-        if (!v3.empty()) PRC_TRY(hipMemcpy(c->it3.p, v3.data(), sizeof(prc_item3) * v3.size(), hipMemcpyHostToDevice), "copy");
+        c->h1p.swap(v1p);
+        c->h1e.swap(v1e);
+        c->h2.swap(v2);
+        c->h3.swap(v3);
+        if ((st = prc_upload_lists(c, nullptr, nullptr, 1))) goto done;
     }
     PRC_TRY(hipStreamSynchronize(s), "sync");
     if (getenv("GMX_PR_DEBUG")) {
@@ -1084,41 +1215,76 @@ const void* pr_cold_partial(const pr_cold* c) { return c ? (const void*) c->cold
 int64_t pr_cold_edges(const pr_cold* c) { return c ? c->Ec : 0; }
 int64_t pr_cold_items(const pr_cold* c) { return c ? c->P2 : 0; }
 
-template <typename S, bool FUSE>
-static void prc_launch(pr_cold* c, const void* contrib, const pr_cold_fuse& fz, hipStream_t s) {
+// phase 1 over the tile classes [k0, k1)
+template <typename S>
+static void prc_gather(pr_cold* c, const void* contrib, int k0, int k1, hipStream_t s) {
     constexpr int TILE = prc_tile_elems((int) sizeof(S));
+    const int64_t span = c->prm.slice - c->prm.T;
+    const int64_t n = c->o1[k1] - c->o1[k0];
+    if (n <= 0) return;
+    const unsigned grid = (unsigned) std::min<int64_t>(c->grid, n);
+    hipLaunchKernelGGL((pr_cold_tile_kernel<S, TILE>), dim3(grid), dim3(PRC_THREADS), 0, s,
+                       (const prc_item1*) c->it1p.p + c->o1[k0], (int) n, c->queue.p, (const S*) contrib, (const int32_t*) c->torg.p, c->prm.nranks, span, c->prm.slice,
+                       c->prm.T, (const uint16_t*) c->srcl.p, (const int32_t*) c->ob.p, (S*) c->val.p, (unsigned) c->P2, c->q1);
+    c->q1 += (uint32_t) n + grid;   // every workgroup claims until its first miss
+}
+
+// phases 2 and 3 of part q
+template <typename S, bool FUSE>
+static void prc_accumulate(pr_cold* c, const pr_cold_fuse& fz, int q, hipStream_t s) {
     constexpr int LIMBS = sizeof(S) == 4 ? 1 : 2;
     constexpr int BINROWS = PRC_LDS_BYTES / 8 / LIMBS;
     const double lo_scale = ldexp(1.0, c->lo_bits);
-    const int64_t span = c->prm.slice - c->prm.T;
-    (void) hipMemsetAsync(c->queue.p, 0, 3 * 64 * sizeof(unsigned int), s);
-    if (c->n1p + c->n1e > 0)
-        hipLaunchKernelGGL((pr_cold_tile_kernel<S, TILE>), dim3((unsigned) std::min<int64_t>(c->grid, c->n1p + c->n1e)), dim3(PRC_THREADS), 0, s,
-                           (const prc_item1*) c->it1p.p, (int) (c->n1p + c->n1e), c->queue.p, (const S*) contrib, (const int32_t*) c->torg.p, c->prm.nranks, span, c->prm.slice,
-                           c->prm.T, (const uint16_t*) c->srcl.p, (const int32_t*) c->ob.p, (S*) c->val.p, (unsigned) c->P2);
-    hipLaunchKernelGGL((pr_cold_accum_kernel<S, BINROWS, LIMBS, FUSE>), dim3((unsigned) std::min<int64_t>(c->grid, c->n2)), dim3(PRC_THREADS), 0, s,
-                       (const prc_item2*) c->it2.p, (int) c->n2, c->queue.p, (const uint16_t*) c->rowl.p, (const S*) c->val.p,
-                       c->prm.nactive, lo_scale, (S*) c->cold.p, c->scratch.p, fz, c->diffp.p);
-    if (c->n3 > 0)
-        hipLaunchKernelGGL((pr_cold_reduce_kernel<S, BINROWS, LIMBS, FUSE>), dim3(BINROWS / 64, (unsigned) c->n3), dim3(1024), 0, s,
-                           (const prc_item3*) c->it3.p, c->prm.nactive, lo_scale, (const unsigned long long*) c->scratch.p, (S*) c->cold.p,
-                           fz, c->diffp.p + c->n2);
+    const int64_t a2 = c->o2[(size_t) q], n2 = c->o2[(size_t) q + 1] - a2;
+    if (n2 > 0) {
+        const unsigned grid = (unsigned) std::min<int64_t>(c->grid, n2);
+        hipLaunchKernelGGL((pr_cold_accum_kernel<S, BINROWS, LIMBS, FUSE>), dim3(grid), dim3(PRC_THREADS), 0, s,
+                           (const prc_item2*) c->it2.p + a2, (int) n2, c->queue.p, (const uint16_t*) c->rowl.p, (const S*) c->val.p,
+                           c->prm.nactive, lo_scale, (S*) c->cold.p, c->scratch.p, fz, c->diffp.p + a2, c->q2);
+        c->q2 += (uint32_t) n2 + grid;
+    }
+    const int64_t a3 = c->o3[(size_t) q], n3 = c->o3[(size_t) q + 1] - a3, few = c->o3few[(size_t) q];
+    if (few > 0)
+        hipLaunchKernelGGL((pr_cold_reduce_few_kernel<S, BINROWS, LIMBS, FUSE>), dim3(BINROWS / 256, (unsigned) few), dim3(256), 0, s,
+                           (const prc_item3*) c->it3.p + a3, c->prm.nactive, lo_scale, (const unsigned long long*) c->scratch.p, (S*) c->cold.p,
+                           fz, c->diffp.p + c->n2 + a3 * (BINROWS / 64));
+    if (n3 > few)
+        hipLaunchKernelGGL((pr_cold_reduce_kernel<S, BINROWS, LIMBS, FUSE>), dim3(BINROWS / 64, (unsigned) (n3 - few)), dim3(1024), 0, s,
+                           (const prc_item3*) c->it3.p + a3 + few, c->prm.nactive, lo_scale, (const unsigned long long*) c->scratch.p, (S*) c->cold.p,
+                           fz, c->diffp.p + c->n2 + (a3 + few) * (BINROWS / 64));
 }
 
-// fuse == NULL: leave the row sums in pr_cold_partial().  Otherwise apply the PageRank update right where a row's sum
-// is finished (needs every edge binned and every bin with rows to own an item) and leave |val - rank| partials in
-// pr_cold_diff_partials().
-int pr_cold_launch(pr_cold* c, const void* contrib, const pr_cold_fuse* fuse, hipStream_t s) {
+// Phase 1 of tile class cls (-1: both): reads the contribution replica, fills the value slots of the class's pairs.
+int pr_cold_gather(pr_cold* c, const void* contrib, int cls, hipStream_t s) {
+    if (!c || c->Ec == 0 || c->n2 == 0) return GMX_OK;
+    const int k0 = cls < 0 ? 0 : cls, k1 = cls < 0 ? 2 : cls + 1;
+    if (c->prm.elem == 4) prc_gather<float>(c, contrib, k0, k1, s);
+    else prc_gather<double>(c, contrib, k0, k1, s);
+    return GMX_OK;
+}
+
+// Phases 2-3 of part `part` (-1: all, in processing order).  fuse == NULL: leave the row sums in pr_cold_partial().
+// Otherwise apply the PageRank update right where a row's sum is finished (needs every edge binned and every bin with
+// rows to own an item) and leave |val - rank| partials in pr_cold_diff_partials().
+int pr_cold_accumulate(pr_cold* c, const pr_cold_fuse* fuse, int part, hipStream_t s) {
     if (!c || c->Ec == 0 || c->n2 == 0) return GMX_OK;
     const pr_cold_fuse none{};
-    if (c->prm.elem == 4) {
-        if (fuse) prc_launch<float, true>(c, contrib, *fuse, s);
-        else prc_launch<float, false>(c, contrib, none, s);
-    } else {
-        if (fuse) prc_launch<double, true>(c, contrib, *fuse, s);
-        else prc_launch<double, false>(c, contrib, none, s);
+    const int q0 = part < 0 ? 0 : part, q1 = part < 0 ? c->nparts : part + 1;
+    for (int q = q0; q < q1; q++) {
+        if (c->prm.elem == 4) {
+            if (fuse) prc_accumulate<float, true>(c, *fuse, q, s);
+            else prc_accumulate<float, false>(c, none, q, s);
+        } else {
+            if (fuse) prc_accumulate<double, true>(c, *fuse, q, s);
+            else prc_accumulate<double, false>(c, none, q, s);
+        }
     }
     return GMX_OK;
+}
+
+int pr_cold_launch(pr_cold* c, const void* contrib, const pr_cold_fuse* fuse, hipStream_t s) {
+    GMX_CHECK(pr_cold_gather(c, contrib, -1, s));
+    return pr_cold_accumulate(c, fuse, -1, s);
 }
 
 const double* pr_cold_diff_partials(const pr_cold* c, int64_t* n) {

@@ -17,6 +17,9 @@ with the sweep split over ranks:
     and every rank copies each finished chunk into all peers' replicas with the copy engines over the
     point-to-point xGMI links (gmx_pr_push_*), which needs no CUs and therefore really runs under the
     persistent sweep kernel; the per-step barrier that orders the ranks is the all-reduce of `diff`;
+  * pushed + pipelined (two row chunks and an engine whose step splits its gather phase, GmxEngine on a plan with
+    every in-edge binned): the exchange of the long tail chunk (most of the bytes) runs under the NEXT step's
+    gather over the hub tiles (most of the work), which needs only the small hub chunk -- see _step_pipelined;
   * `diff` is a 1-element fp64 all-reduce(SUM) -- the ATOMIC_ADD<double>(&diff, diff_prv) of the
     emitted code with ranks in place of threads.
 
@@ -82,6 +85,15 @@ class GmxEngine:
     def push_join(self):
         self.state.push_join(None)
 
+    def push_join_chunk(self, chunk, stream=None):
+        self.state.push_join_chunk(chunk, stream)
+
+    def gather_classes(self):
+        return self.state.gather_classes()
+
+    def step_gather(self, tile_class):
+        self.state.step_gather(tile_class, None)
+
     def contrib_slice(self):
         return self._wrap(self.state.contrib_slice())
 
@@ -105,7 +117,7 @@ class DistPageRank:
     production path) or "host" (stream sync + host barrier; for ranks sharing one GPU, where RCCL cannot run)."""
 
     def __init__(self, engine, group=None, always_exchange=False, exchange="collective", barrier="collective",
-                 verify_push=True):
+                 verify_push=True, pipeline=True):
         self.engine = engine
         self.group = group
         self.initialized = dist.is_available() and dist.is_initialized()
@@ -120,6 +132,19 @@ class DistPageRank:
         self.exchange = "collective"
         if exchange in ("push", "auto") and self.world > 1:
             self.exchange = "push" if self._setup_push(exchange == "push") else "collective"
+        # pipelined pushed step: its second barrier (tail chunk landed everywhere) runs beside the per-step one, so
+        # it gets a process group -- i.e. a communicator and stream -- of its own.  Every rank decides the same way.
+        self.pipeline = pipeline
+        self._early_group = None
+        self._early_work = None
+        self._early_token = None
+        self._side = None
+        if pipeline and self.exchange == "push":
+            mine = int(hasattr(engine, "gather_classes") and engine.gather_classes() == 2)
+            flags = [None] * self.world
+            dist.all_gather_object(flags, mine, group=self.group)
+            if all(flags):
+                self._early_group = dist.new_group(backend=dist.get_backend(group))
 
     def _setup_push(self, required):
         """Pass the replica handles around and map the peers'; every rank must succeed or none uses it."""
@@ -171,8 +196,60 @@ class DistPageRank:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         self._diff = t
 
+    def _can_pipeline(self, chunks):
+        return self._early_group is not None and chunks == 2 and (self.push_verified or not self.verify_push)
+
+    def _early_barrier(self, chunk):
+        """Issued right after chunk `chunk` (every one but the last) has been pushed: completes once every rank's
+        copies of it have landed.  Does not hold up this stream; _wait_early() is where the result is needed."""
+        eng = self.engine
+        if self.barrier == "host":
+            torch.cuda.synchronize() if torch.cuda.is_available() else None
+            dist.barrier(group=self._early_group)
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+            self._early_token = torch.zeros(1, device="cuda")
+        with torch.cuda.stream(self._side):
+            eng.push_join_chunk(chunk, self._side.cuda_stream)     # the side stream waits for the copies ...
+            # ... and the collective (on the second group's own stream) for the side stream
+            self._early_work = dist.all_reduce(self._early_token, group=self._early_group, async_op=True)
+
+    def _wait_early(self):
+        if self._early_work is not None:
+            self._early_work.wait()        # orders the current stream after the collective; the host goes on
+            self._early_work = None
+
+    def _step_pipelined(self):
+        """Two chunks: 0 = tail of the rank's range (most rows, a third of the edges, most of the BYTES),
+        1 = hub (most of the work, few bytes).  Only the gather phase of a step reads the peers' contributions:
+          gather(0)  hub tiles    needs every rank's hub chunk of the previous step  -> that step's diff all-reduce
+          gather(1)  other tiles  needs the tail chunks too                          -> the early barrier
+        so the tail chunk travels under gather(0) of the next step.  Replica reuse (double buffered) is safe: a
+        rank pushes into a replica only after a barrier that every rank passed after its last read of it."""
+        eng = self.engine
+        eng.step_gather(0)
+        self._wait_early()
+        eng.step_gather(1)
+        eng.step_chunk(0)
+        eng.push_chunk(0)
+        self._early_barrier(0)
+        eng.step_chunk(1)
+        eng.push_chunk(1)
+        if self.barrier == "host":
+            eng.push_join()
+        else:
+            eng.push_join_chunk(1)         # this stream waits for the hub copies only
+        self._rank_barrier()
+
+    def drain(self):
+        """Everything issued so far (incl. the travelling tail chunk) ordered before what this stream does next."""
+        self._wait_early()
+
     def _step_pushed(self, chunks):
         eng = self.engine
+        if self._can_pipeline(chunks):
+            return self._step_pipelined()
         for c in range(chunks):
             eng.step_chunk(c)
             eng.push_chunk(c)      # copies start when the chunk is done, the stream goes on with the next one
@@ -220,6 +297,7 @@ class DistPageRank:
             dist.all_gather_into_tensor(full, mine, group=self.group)
 
     def reset(self, d=0.85):
+        self.drain()
         self.engine.reset(d)
         self.cnt = 0
         self._exchange()

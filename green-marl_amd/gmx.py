@@ -52,6 +52,7 @@ EXPORTS = [
     "gmx_pr_set_chunks", "gmx_pr_num_chunks", "gmx_pr_chunk_range", "gmx_pr_step_chunk", "gmx_pr_contrib_next_full",
     "gmx_ipc_export", "gmx_ipc_open", "gmx_ipc_close", "gmx_pr_contrib_buffers", "gmx_pr_set_peers",
     "gmx_pr_push_chunk", "gmx_pr_push_current", "gmx_pr_push_join",
+    "gmx_pr_gather_classes", "gmx_pr_step_gather", "gmx_pr_push_join_chunk", "gmx_pr_gather_items",
     "gmx_pr_timing", "gmx_pr_kernel_time", "gmx_pr_kernel_name", "gmx_pr_default_options", "gmx_pr_cold_info",
 ]
 
@@ -127,6 +128,10 @@ def lib():
         L.gmx_pr_push_chunk.argtypes = [vp, C.c_int, vp]
         L.gmx_pr_push_current.argtypes = [vp, vp]
         L.gmx_pr_push_join.argtypes = [vp, vp]
+        L.gmx_pr_gather_classes.argtypes = [vp, C.POINTER(C.c_int)]
+        L.gmx_pr_step_gather.argtypes = [vp, C.c_int, vp]
+        L.gmx_pr_gather_items.argtypes = [vp, C.c_int, C.POINTER(i64)]
+        L.gmx_pr_push_join_chunk.argtypes = [vp, C.c_int, vp]
         L.gmx_pr_set_chunks.argtypes = [vp, C.c_int]
         L.gmx_pr_num_chunks.argtypes = [vp, C.POINTER(C.c_int)]
         L.gmx_pr_chunk_range.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(i64)]
@@ -478,6 +483,24 @@ class PageRankState:
 
     def push_join(self, stream=None):
         _ck(lib().gmx_pr_push_join(self._h, stream))
+
+    def push_join_chunk(self, chunk, stream=None):
+        """`stream` waits for the copies of one chunk only."""
+        _ck(lib().gmx_pr_push_join_chunk(self._h, int(chunk), stream))
+
+    def gather_classes(self):
+        """2 when the step can be pipelined (every in-edge binned: step_gather(0/1) ahead of step_chunk), else 0."""
+        n = C.c_int(0)
+        _ck(lib().gmx_pr_gather_classes(self._h, C.byref(n)))
+        return n.value
+
+    def gather_items(self, tile_class):
+        n = C.c_int64(0)
+        _ck(lib().gmx_pr_gather_items(self._h, int(tile_class), C.byref(n)))
+        return n.value
+
+    def step_gather(self, tile_class, stream=None):
+        _ck(lib().gmx_pr_step_gather(self._h, int(tile_class), stream))
 
     def set_chunks(self, chunks):
         _ck(lib().gmx_pr_set_chunks(self._h, int(chunks)))

@@ -241,6 +241,20 @@ int gmx_pr_set_peers(gmx_pr_t* p, void* const* peer_buf0, void* const* peer_buf1
 int gmx_pr_push_chunk(gmx_pr_t* p, int chunk, void* stream);
 int gmx_pr_push_current(gmx_pr_t* p, void* stream);
 int gmx_pr_push_join(gmx_pr_t* p, void* stream);
+/* Pipelined form of the pushed step (plans with every in-edge binned: gmx_pr_gather_classes returns 2, else 0).
+ * Phase 1 of the binned sweep is the only part of a step that reads the peers' contributions, and most of its work
+ * sits in the tiles of the hub sources, whose contributions are the small LAST chunk of every rank's exchange.  So:
+ *   gmx_pr_step_gather(p, 0, s)   phase 1 over the tiles that hold hub sources only   (needs the peers' last chunk)
+ *   gmx_pr_step_gather(p, 1, s)   phase 1 over the other tiles                        (needs all chunks)
+ *   gmx_pr_step_chunk(p, c, s) / gmx_pr_push_chunk(p, c, s) for c = 0 .. chunks-1 as before (the chunks' copies
+ *   alternate between two sets of copy streams, so the hub chunk does not queue behind the tail chunk)
+ * and the caller may start class 0 of the next step as soon as every rank's LAST chunk has landed
+ * (gmx_pr_push_join_chunk(p, chunks-1, s) + its barrier), while the earlier chunks are still travelling; class 1
+ * waits for those.  Without the gather calls gmx_pr_step_chunk(p, 0, s) enqueues phase 1 itself. */
+int gmx_pr_gather_classes(gmx_pr_t* p, int* classes);
+int gmx_pr_gather_items(gmx_pr_t* p, int tile_class, int64_t* items);   /* phase-1 work items of a class (set by gmx_pr_set_chunks) */
+int gmx_pr_step_gather(gmx_pr_t* p, int tile_class, void* stream);
+int gmx_pr_push_join_chunk(gmx_pr_t* p, int chunk, void* stream);
 /* Device pointer + element count of the slice of the *current* contribution
  * vector this rank produced in the last step (for the exchange), and of the
  * whole replica. */

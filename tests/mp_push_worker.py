@@ -14,6 +14,9 @@ for p in (os.path.join(HERE, "..", "green-marl_amd"), os.path.join(HERE, "..", "
 
 def main():
     scale, chunks, elem, iters = (int(a) for a in sys.argv[1:5])
+    binned = len(sys.argv) > 5 and sys.argv[5] == "binned"     # every in-edge binned: the pipelined pushed step
+    if binned:
+        os.environ["GMX_PR_COLD"] = "0"
     import torch
     import torch.distributed as dist
     import gmx
@@ -25,12 +28,18 @@ def main():
     gmx.require_device()
     og = po.rmat_graph(scale, permute=True)
     g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
-    options = gmx.GMX_PR_RELABEL | gmx.GMX_PR_HOT_LDS | gmx.GMX_PR_SLICED
+    options = gmx.GMX_PR_RELABEL | gmx.GMX_PR_HOT_LDS | gmx.GMX_PR_SLICED | (gmx.GMX_PR_COLD_PB if binned else 0)
     eng = GmxEngine(gmx, g, elem, rank, world, options)
     assert eng.set_chunks(chunks) == chunks
     pr = DistPageRank(eng, exchange="push", barrier="host")
     assert pr.exchange == "push"
+    piped = []
+    if binned:
+        assert eng.gather_classes() == 2 and pr._early_group is not None
+        orig = pr._step_pipelined
+        pr._step_pipelined = lambda: (piped.append(1), orig())[1]
     cnt, diff = pr.run(1e-300, 0.85, iters)
+    assert len(piped) == (cnt if binned and chunks == 2 else 0)
     out = np.zeros(og.N, dtype=np.float32 if elem == 4 else np.float64)
     eng.download(out)                      # fills the vertices this rank owns
     t = torch.from_numpy(out.astype(np.float64))

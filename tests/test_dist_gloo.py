@@ -138,6 +138,43 @@ class SharedFileEngine(NumpyEngine):
         pass
 
 
+class PipelinedFileEngine(SharedFileEngine):
+    """SharedFileEngine whose step reads the replica only in two gather calls, like the binned GPU step
+    (gmx_pr_step_gather): class 0 takes every rank's LAST chunk (the hub piece), class 1 the rest; the chunks are
+    then computed from that snapshot.  A gather issued before its pieces have landed gives wrong ranks."""
+
+    def gather_classes(self):
+        return 2
+
+    def push_join_chunk(self, c, stream=None):
+        pass
+
+    def step_gather(self, cls):
+        if cls == 0:
+            self.step_next = 1 - self.cur
+            self.snap = np.full(self.slice * self.world, np.nan)
+        off, cnt = self.chunk_range(self.nchunks - 1)
+        hub = np.zeros(self.slice * self.world, dtype=bool)
+        for r in range(self.world):
+            hub[r * self.slice + off:r * self.slice + off + cnt] = True
+        pick = hub if cls == 0 else ~hub
+        self.snap[pick] = self.contrib[self.cur].numpy()[pick]
+        self.gathered = getattr(self, "gathered", 0) | (1 << cls)
+
+    def step_chunk(self, c):
+        if c == 0:
+            for cls in (0, 1):      # not driven through the pipelined order: gather here, like gmx_pr_step_chunk(0)
+                if not getattr(self, "gathered", 0) & (1 << cls):
+                    self.step_gather(cls)
+            self.gathered = 0
+        live, cur = self.contrib[self.cur], self.cur
+        self.contrib[cur] = torch.from_numpy(self.snap)     # what the gathers saw, not what is there now
+        try:
+            NumpyEngine.step_chunk(self, c)                 # (flips self.cur after the last chunk)
+        finally:
+            self.contrib[cur] = live
+
+
 class BrokenPushEngine(SharedFileEngine):
     """Peer copies that silently land nowhere: DistPageRank's one-time check must notice and fall back."""
 
@@ -153,7 +190,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, scale, out_dir, chunks=1, push=False, broken=False):
+def _worker(rank, world, port, scale, out_dir, chunks=1, push=False, broken=False, pipelined=False):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (os.path.join(here, "..", "green-marl_amd"), os.path.join(here, "..", "oracle")):
@@ -163,11 +200,18 @@ def _worker(rank, world, port, scale, out_dir, chunks=1, push=False, broken=Fals
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = po.rmat_graph(scale, permute=True)
-    eng = (BrokenPushEngine if broken else SharedFileEngine)(g, rank, world, out_dir) if push else NumpyEngine(g, rank, world)
+    cls = BrokenPushEngine if broken else PipelinedFileEngine if pipelined else SharedFileEngine
+    eng = cls(g, rank, world, out_dir) if push else NumpyEngine(g, rank, world)
     eng.set_chunks(chunks)
     pr = DistPageRank(eng, exchange="push", barrier="host") if push else DistPageRank(eng)
     assert pr.exchange == ("push" if push else "collective")
+    if pipelined:
+        calls = []
+        orig = pr._step_pipelined
+        pr._step_pipelined = lambda: (calls.append(1), orig())[1]
     cnt, diff = pr.run(0.001, 0.85, 100)
+    if pipelined:
+        assert (len(calls) == cnt) == (chunks == 2)      # the pipelined order is what ran (two chunks), else the plain one
     assert pr.exchange == ("push" if push and not broken else "collective")   # broken copies: fell back
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), eng.rank_v)
     np.save(os.path.join(out_dir, "meta%d.npy" % rank), np.array([cnt, diff, eng.lo, eng.hi]))
@@ -175,17 +219,21 @@ def _worker(rank, world, port, scale, out_dir, chunks=1, push=False, broken=Fals
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,chunks,push,broken", [(2, 1, False, False), (3, 1, False, False), (2, 4, False, False),
-                                                       (3, 3, False, False), (2, 1, True, False), (3, 2, True, False),
-                                                       (2, 2, True, True)])
-def test_dist_pagerank_gloo(tmp_path, world, chunks, push, broken):
+@pytest.mark.parametrize("world,chunks,push,broken,pipelined", [
+    (2, 1, False, False, False), (3, 1, False, False, False), (2, 4, False, False, False), (3, 3, False, False, False),
+    (2, 1, True, False, False), (3, 2, True, False, False), (2, 2, True, True, False),
+    (2, 2, True, False, True), (3, 2, True, False, True), (2, 3, True, False, True)])
+def test_dist_pagerank_gloo(tmp_path, world, chunks, push, broken, pipelined):
     """chunks > 1: the sweep is enqueued in row chunks and each chunk's piece is all-gathered (async) while
     the next chunk is computed -- the overlap path the GPU ranks take for N > 1.
     push: the exchange by direct copies into the peers' replicas (files here, hipIpc-mapped HBM on the GPUs),
     ordered by the per-step all-reduce of diff.  broken: the copies do nothing -- the first exchange is checked
-    against a collective one and every rank falls back to the all-gather."""
+    against a collective one and every rank falls back to the all-gather.
+    pipelined: an engine whose step reads the peers' contributions in two gather calls (hub pieces / the rest),
+    driven in DistPageRank's pipelined order -- gather(0) right after the per-step barrier, gather(1) after the early
+    barrier of the previous step's tail chunk."""
     scale = 11
-    mp.spawn(_worker, args=(world, _free_port(), scale, str(tmp_path), chunks, push, broken), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), scale, str(tmp_path), chunks, push, broken, pipelined), nprocs=world, join=True)
     g = po.rmat_graph(scale, permute=True)
     want, it, want_diff = po.pagerank(g, 0.001, 0.85, 100, nthreads=1)
     got = np.zeros(g.N)

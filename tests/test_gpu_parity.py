@@ -501,10 +501,79 @@ def test_pagerank_cold_sources_binned(gmx, scale, nranks, chunks, elem, hot, chu
     g.free()
 
 
-@pytest.mark.parametrize("world,chunks,elem", [(3, 2, 8), (2, 1, 4)])
-def test_peer_push_exchange_between_processes(gmx, world, chunks, elem):
+@pytest.mark.parametrize("scale,nranks,elem", [(18, 4, 4), (17, 2, 8), (19, 8, 4), (16, 3, 8), (22, 2, 4)])
+def test_pagerank_pipelined_gather_order(gmx, scale, nranks, elem, monkeypatch):
+    """The pipelined form of the pushed step (gmx_pr_step_gather): phase 1 over the class-0 tiles may run while the
+    peers' TAIL chunks of the previous step are still travelling.  N rank states in one process; the tail pieces
+    are withheld -- the peers' copies of them hold NaN -- until every rank's gather(0) has run, then delivered
+    before gather(1).  A class-0 tile that read a single live tail source would poison the ranks."""
+    import torch
+    monkeypatch.setenv("GMX_PR_COLD", "0")
+    monkeypatch.setenv("GMX_PR_COLD_CHUNK", "16")
+    og = po.rmat_graph(scale, permute=True)
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    iters = 6
+    want, it, want_diff = po.pagerank(og, 1e-300, 0.85, iters)
+    options = gmx.GMX_PR_RELABEL | gmx.GMX_PR_HOT_LDS | gmx.GMX_PR_SLICED | gmx.GMX_PR_COLD_PB
+    states = [gmx.PageRankState(g, elem, r, nranks, options) for r in range(nranks)]
+    assert all(s.gather_classes() == 2 for s in states)
+    for s in states:
+        assert s.set_chunks(2) == 2
+        s.reset(0.85)
+    if scale >= 22:     # hub pieces wider than an LDS tile: there ARE tiles of hub sources only
+        assert all(s.gather_items(0) > 0 and s.gather_items(1) > 0 for s in states)
+    (t_off, t_cnt), (h_off, h_cnt) = states[0].chunk_range(0), states[0].chunk_range(1)   # tail is processed first
+    assert h_off == 0 and t_off == h_cnt and t_cnt > 0 and h_cnt > 0
+    n = torch.as_tensor(states[0].contrib_slice(), device="cuda").numel()
+
+    def deliver(fulls, off, cnt):
+        for dst in fulls:
+            for r, src in enumerate(fulls):
+                if dst is not src:
+                    dst[r * n + off:r * n + off + cnt].copy_(src[r * n + off:r * n + off + cnt])
+
+    def withhold(fulls, off, cnt):
+        for q, dst in enumerate(fulls):
+            for r in range(nranks):
+                if r != q:
+                    dst[r * n + off:r * n + off + cnt] = float("nan")
+
+    cur = [torch.as_tensor(s.contrib_full(), device="cuda") for s in states]
+    deliver(cur, h_off, h_cnt)
+    withhold(cur, t_off, t_cnt)
+    torch.cuda.synchronize()
+    for _ in range(iters):
+        nxt = [torch.as_tensor(s.contrib_next_full(), device="cuda") for s in states]
+        for s in states:
+            s.step_gather(0)
+        torch.cuda.synchronize()
+        deliver(cur, t_off, t_cnt)            # the tail chunk of the previous step lands only now
+        for s in states:
+            s.step_gather(1)
+        for s in states:
+            s.step_chunk(0)
+        withhold(nxt, t_off, t_cnt)           # ... and this step's stays away until the next gather(0) has run
+        for s in states:
+            s.step_chunk(1)
+        deliver(nxt, h_off, h_cnt)
+        torch.cuda.synchronize()
+        cur = nxt
+    out = np.zeros(og.N, dtype=np.float64 if elem == 8 else np.float32)
+    for s in states:
+        s.download(out)
+    diff = sum(s.diff() for s in states)
+    assert rel_err(out, want) < (PR_RTOL_F64 if elem == 8 else PR_RTOL_F32)
+    assert abs(diff - want_diff) <= (1e-9 if elem == 8 else 1e-3) * max(want_diff, 1e-30) + 1e-15
+    for s in states:
+        s.free()
+    g.free()
+
+
+@pytest.mark.parametrize("world,chunks,elem,binned", [(3, 2, 8, ""), (2, 1, 4, ""), (3, 2, 4, "binned"), (2, 2, 8, "binned"), (2, 1, 4, "binned")])
+def test_peer_push_exchange_between_processes(gmx, world, chunks, elem, binned):
     """The N > 1 exchange by direct copies into the peers' hipIpc-mapped replicas, with real processes (one
-    per rank, sharing this box's single GPU; see tests/mp_push_worker.py)."""
+    per rank, sharing this box's single GPU; see tests/mp_push_worker.py).  binned: plans with every in-edge
+    binned, which DistPageRank drives in the pipelined order when the step has two chunks."""
     import socket
     import subprocess
     import sys
@@ -516,7 +585,7 @@ def test_peer_push_exchange_between_processes(gmx, world, chunks, elem):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, worker, "15", str(chunks), str(elem), "8"], env=env,
+        procs.append(subprocess.Popen([sys.executable, worker, "15", str(chunks), str(elem), "8", binned], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
