@@ -177,7 +177,8 @@ def main():
         # chunked step: the low-degree tail of the rank's range is reduced first and travels while the hubs
         # (most of the sweep) are reduced
         chunks = engine.set_chunks(args.chunks if args.chunks > 0 else 2)
-    pr = DistPageRank(engine, always_exchange=force_coll, exchange=args.exchange if world > 1 else "collective")
+    pr = DistPageRank(engine, always_exchange=force_coll, exchange=args.exchange if world > 1 else "collective",
+                      pipeline=os.environ.get("GMX_BENCH_PIPELINE", "1") != "0")
     pr.reset(0.85)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
@@ -206,6 +207,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt * 1e3 / args.steps
+    # outside the timed region: after the last step every rank's replica must hold exactly what an all-gather of the
+    # owned slices delivers (the pushed, pipelined exchange is ordered by barriers only -- this is its check)
+    exchange_check = None
+    if world > 1 and pr.exchange == "push":
+        pr.drain()
+        torch.cuda.synchronize()
+        dist.barrier()
+        ok = torch.tensor([1.0 if pr._push_matches_collective() else 0.0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        exchange_check = "replicas equal an all-gather of the owned slices on every rank" if float(ok.item()) == 1.0 else "MISMATCH"
+    pipelined = bool(world > 1 and pr.exchange == "push" and pr._can_pipeline(chunks))
     work = engine.state.work()
     gteps = graph.E / (ms_per_step * 1e-3) / 1e9
     achieved = work["algorithmic_bytes"] / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -245,7 +257,9 @@ def main():
                        "partition": "1-D vertex, %d rank(s)" % world,
                        "exchange": "none" if world == 1 and not force_coll else
                                    ("peer copies over xGMI (hipIpc, copy engines), %d row chunk(s), barrier = all-reduce of diff"
-                                    if pr.exchange == "push" else "RCCL all-gather of contribution slices, %d row chunk(s)") % chunks,
+                                    if pr.exchange == "push" else "RCCL all-gather of contribution slices, %d row chunk(s)") % chunks
+                                   + ("; pipelined: the tail chunk travels under the next step's gather over the hub tiles" if pipelined else ""),
+                       "exchange_check": exchange_check,
                        "options": options, "setup_s": round(setup_s, 2), "last_diff": last_diff},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

@@ -210,6 +210,7 @@ class DistPageRank:
         if self._side is None:
             self._side = torch.cuda.Stream()
             self._early_token = torch.zeros(1, device="cuda")
+            self._side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._side):
             eng.push_join_chunk(chunk, self._side.cuda_stream)     # the side stream waits for the copies ...
             # ... and the collective (on the second group's own stream) for the side stream

@@ -125,7 +125,9 @@ typedef struct {
  * rank_host[V] is caller-owned (pagerank_main.cc:18-25) and written on return. */
 int gmx_pagerank_f64(gmx_graph_t* g, double e, double d, int32_t max_iter,
                      double* rank_host, gmx_stats_t* stats);
-/* Node_Prop<Float> variant (BASELINE config 2): fp32 storage, fp64 row sums. */
+/* Node_Prop<Float> variant (BASELINE config 2): fp32 STORAGE, row sums in fp64 / 64-bit fixed point, one rounding
+ * per vertex.  Within 1e-6 relative of the fp64 result; not bit- or iteration-comparable with what gm_comp would emit
+ * for a Float property (fp32 sums in thread order), whose iteration count near the threshold e may differ. */
 int gmx_pagerank_f32(gmx_graph_t* g, float e, float d, int32_t max_iter,
                      float* rank_host, gmx_stats_t* stats);
 
