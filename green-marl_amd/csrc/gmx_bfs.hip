@@ -63,29 +63,6 @@ __global__ void bfs_init_kernel(int32_t* __restrict__ dist, int64_t V, int32_t r
     for (; i < V; i += stride) dist[i] = (i == root) ? 0 : INT_MAX;
 }
 
-__device__ __forceinline__ void bfs_visit(int32_t s, int32_t next_level, int32_t* __restrict__ dist,
-                                          int32_t* __restrict__ next_q, bfs_counters* __restrict__ ctr,
-                                          const int32_t* __restrict__ begin) {
-    // <s.dist_nxt; s.updated_nxt> min= <n.dist + 1; True>   (hop_dist.gm:21)
-    bool won = false;
-    if (dist[s] == INT_MAX) won = (atomicMin(&dist[s], next_level) == INT_MAX);
-    unsigned long long m = __ballot(won);
-    if (m) {
-        int lane = threadIdx.x & 63;
-        int leader = __ffsll((long long) m) - 1;
-        unsigned long long deg = won ? (unsigned long long) (begin[s + 1] - begin[s]) : 0ull;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) deg += __shfl_xor(deg, o, 64);
-        unsigned long long base = 0;
-        if (lane == leader) {
-            base = atomicAdd(&ctr->next_count, (unsigned long long) __popcll(m));
-            if (deg) atomicAdd(&ctr->next_edges, deg);
-        }
-        base = __shfl(base, leader, 64);
-        if (won) next_q[base + __popcll(m & ((1ULL << lane) - 1))] = s;
-    }
-}
-
 #define BFS_ITEMS 2048   // merge-path items (frontier vertices + their out-edges) per workgroup
 
 __global__ void bfs_degree_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ q, int64_t n,
@@ -154,7 +131,16 @@ bfs_topdown_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict_
     __shared__ int64_t s_off[BFS_ITEMS + 2];
     __shared__ int32_t s_row[BFS_ITEMS + 2];
     __shared__ int64_t s_split[2][2];
+    // the vertices this workgroup discovers wait here: the queue tail is claimed ONCE per workgroup (a claim per wave
+    // and round -- two atomics on one cache line -- was most of a top-down level out of a hub: 42 K waves, ~90 per us)
+    __shared__ int32_t s_win[BFS_ITEMS];
+    __shared__ unsigned int s_nwin;
+    __shared__ unsigned long long s_deg, s_base;
     const int tid = threadIdx.x;
+    if (tid == 0) {
+        s_nwin = 0;
+        s_deg = 0;
+    }
     if (tid < 2) {   // merge-path split of diagonals k*ITEMS and (k+1)*ITEMS
         int64_t dk = ((int64_t) blockIdx.x + tid) * BFS_ITEMS;
         if (dk > n + m) dk = n + m;
@@ -176,7 +162,7 @@ bfs_topdown_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict_
     }
     if (tid == 0) s_off[nv] = m + 1;   // sentinel
     __syncthreads();
-    unsigned long long inspected = 0;
+    unsigned long long inspected = 0, deg = 0;
     for (int64_t x = e0 + tid; x < e1; x += BFS_THREADS) {
         // frontier slot of edge x: last i with s_off[i] <= x
         int lo = 0, hi = nv - 1;
@@ -186,11 +172,40 @@ bfs_topdown_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict_
         }
         int32_t s = node_idx[(int64_t) s_row[lo] + (x - s_off[lo])];
         inspected++;
-        bfs_visit(s, level + 1, dist, next_q, ctr, begin);
+        // <s.dist_nxt; s.updated_nxt> min= <n.dist + 1; True>   (hop_dist.gm:21)
+        bool won = false;
+        if (dist[s] == INT_MAX) won = (atomicMin(&dist[s], level + 1) == INT_MAX);
+        const unsigned long long mw = __ballot(won);
+        if (mw) {
+            const int lane = tid & 63;
+            const int leader = __ffsll((long long) mw) - 1;
+            unsigned int at = 0;
+            if (lane == leader) at = atomicAdd(&s_nwin, (unsigned int) __popcll(mw));
+            at = __shfl(at, leader, 64);
+            if (won) {
+                s_win[at + __popcll(mw & ((1ULL << lane) - 1))] = s;
+                deg += (unsigned long long) (begin[s + 1] - begin[s]);
+            }
+        }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) inspected += __shfl_down(inspected, o, 64);
-    if ((tid & 63) == 0) bfs_count(ctr, inspected, 0);
+    for (int o = 32; o > 0; o >>= 1) {
+        inspected += __shfl_down(inspected, o, 64);
+        deg += __shfl_down(deg, o, 64);
+    }
+    if ((tid & 63) == 0) {
+        bfs_count(ctr, inspected, 0);
+        if (deg) atomicAdd(&s_deg, deg);
+    }
+    __syncthreads();
+    const unsigned int nwin = s_nwin;
+    if (nwin == 0) return;   // (workgroup-uniform)
+    if (tid == 0) {
+        s_base = atomicAdd(&ctr->next_count, (unsigned long long) nwin);
+        if (s_deg) atomicAdd(&ctr->next_edges, s_deg);
+    }
+    __syncthreads();
+    for (unsigned int i = tid; i < nwin; i += BFS_THREADS) next_q[s_base + i] = s_win[i];
 }
 
 // frontier bitmap of a level straight from dist[] (coalesced reads, one __ballot per 64 vertices, no atomics)
@@ -225,16 +240,39 @@ __global__ void bfs_level_queue_kernel(const int32_t* __restrict__ dist, int64_t
     }
 }
 
-// queue of the vertices whose bit is set (the frontier a bottom-up level left behind): one thread per 64-bit
-// word -- 8 bytes per 64 vertices to read instead of their dist[] entries, and nothing to do for empty words
-__global__ void bfs_bitmap_queue_kernel(const unsigned long long* __restrict__ bm64, int64_t words,
-                                        int32_t* __restrict__ q, unsigned long long* __restrict__ qcount) {
-    int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
-    for (; w < words; w += stride) {
+// queue of the vertices whose bit is set (the frontier a bottom-up level left behind): 8 bytes per 64 vertices to
+// read instead of their dist[] entries.  A block takes a contiguous run of words, counts its bits, claims its piece of
+// the queue with ONE atomic (atomics on one address retire at ~90 per microsecond: a claim per word cost 170 us at
+// RMAT-26, one per wave as much) and walks its words again to write.
+__global__ void __launch_bounds__(BFS_THREADS)
+bfs_bitmap_queue_kernel(const unsigned long long* __restrict__ bm64, int64_t words,
+                        int32_t* __restrict__ q, unsigned long long* __restrict__ qcount) {
+    __shared__ unsigned int s_wave[BFS_THREADS / 64];
+    __shared__ unsigned long long s_base;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t per = (words + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t) blockIdx.x * per, hi = lo + per < words ? lo + per : words;
+    unsigned int c = 0;
+    for (int64_t w = lo + threadIdx.x; w < hi; w += BFS_THREADS) c += (unsigned int) __popcll(bm64[w]);
+    // thread t owns the words lo + t, lo + t + T, ...: its queue entries follow those of the threads before it
+    unsigned int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    unsigned int before = 0, total = 0;
+    for (int i = 0; i < BFS_THREADS / 64; i++) {
+        if (i < wv) before += s_wave[i];
+        total += s_wave[i];
+    }
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(qcount, (unsigned long long) total) : 0ull;
+    __syncthreads();
+    unsigned long long at = s_base + before + (incl - c);
+    for (int64_t w = lo + threadIdx.x; w < hi; w += BFS_THREADS) {
         unsigned long long m = bm64[w];
-        if (!m) continue;
-        unsigned long long at = atomicAdd(qcount, (unsigned long long) __popcll(m));
         while (m) {
             const int b = __ffsll((long long) m) - 1;
             m &= m - 1;
@@ -253,7 +291,14 @@ __global__ void bfs_edges_reached_kernel(const int32_t* __restrict__ dist, const
         if (dist[v] != INT_MAX) acc += (unsigned long long) (begin[v + 1] - begin[v]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+    __shared__ unsigned long long s_acc[BFS_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) s_acc[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {   // one atomic per block
+        unsigned long long t = 0;
+        for (int i = 0; i < (int) (blockDim.x >> 6); i++) t += s_acc[i];
+        if (t) atomicAdd(out, t);
+    }
 }
 
 static int grid_for(int64_t n, int block = BFS_THREADS, int max_blocks = 256 * 8) {
@@ -501,7 +546,7 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
         if (b->frontier_is_bitmap) {   // back from bottom-up: rebuild the queue and its edge offsets
             GMX_HIP(hipMemsetAsync(b->qcount.p, 0, sizeof(unsigned long long), 0));
             if (b->frontier_bm_valid)   // the frontier is the bitmap the last bottom-up level found
-                hipLaunchKernelGGL(bfs_bitmap_queue_kernel, dim3(grid_for((V + 63) / 64, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
+                hipLaunchKernelGGL(bfs_bitmap_queue_kernel, dim3(grid_for((V + 63) / 64, BFS_THREADS, 256 * 4)), dim3(BFS_THREADS), 0, 0,
                                    (const unsigned long long*) b->bm[b->fr].p, (V + 63) / 64, b->cur_q, b->qcount.p);
             else
                 hipLaunchKernelGGL(bfs_level_queue_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,

@@ -14,7 +14,7 @@ import os
 import sys
 from collections import defaultdict
 
-STEP_KERNELS = ["pr_cold_tile_kernel", "pr_cold_accum_kernel", "pr_cold_reduce_kernel", "pr_diff_reduce2_kernel",
+STEP_KERNELS = ["pr_cold_tile_kernel", "pr_cold_accum_kernel", "pr_cold_reduce_few_kernel", "pr_cold_reduce_kernel", "pr_diff_reduce2_kernel",
                 "pr_wave_sliced_kernel", "pr_wave_kernel", "pr_sliced_fixup_kernel", "pr_fixup_kernel",
                 "pr_combine_kernel", "pr_diff_reduce_kernel"]
 
