@@ -698,7 +698,11 @@ sssp_relax_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__
     __shared__ int32_t s_row[BFS_ITEMS + 2];
     __shared__ int32_t s_dist[BFS_ITEMS + 2];
     __shared__ int64_t s_split[2][2];
+    __shared__ int32_t s_win[BFS_ITEMS];   // (one queue-tail claim per workgroup, as in bfs_topdown_kernel)
+    __shared__ unsigned int s_nwin;
+    __shared__ unsigned long long s_base;
     const int tid = threadIdx.x;
+    if (tid == 0) s_nwin = 0;
     if (tid < 2) {
         int64_t dk = ((int64_t) blockIdx.x + tid) * BFS_ITEMS;
         if (dk > n + m) dk = n + m;
@@ -739,15 +743,21 @@ sssp_relax_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__
         if (mk) {
             const int lane = threadIdx.x & 63;
             const int leader = __ffsll((long long) mk) - 1;
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(&ctr->next_count, (unsigned long long) __popcll(mk));
-            base = __shfl(base, leader, 64);
-            if (won) next_q[base + __popcll(mk & ((1ULL << lane) - 1))] = s;
+            unsigned int at = 0;
+            if (lane == leader) at = atomicAdd(&s_nwin, (unsigned int) __popcll(mk));
+            at = __shfl(at, leader, 64);
+            if (won) s_win[at + __popcll(mk & ((1ULL << lane) - 1))] = s;
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) inspected += __shfl_down(inspected, o, 64);
     if ((tid & 63) == 0) bfs_count(ctr, inspected, 0);
+    __syncthreads();
+    const unsigned int nwin = s_nwin;
+    if (nwin == 0) return;   // (workgroup-uniform)
+    if (tid == 0) s_base = atomicAdd(&ctr->next_count, (unsigned long long) nwin);
+    __syncthreads();
+    for (unsigned int i = tid; i < nwin; i += BFS_THREADS) next_q[s_base + i] = s_win[i];
 }
 
 __global__ void sssp_init_kernel(int32_t* __restrict__ dist, int32_t* __restrict__ stamp, int64_t V, int32_t root) {
