@@ -220,6 +220,17 @@ __global__ void bfs_level_bitmap_kernel(const int32_t* __restrict__ dist, int64_
     }
 }
 
+// frontier bitmap from the frontier QUEUE (what a top-down level leaves): one atomicOr per vertex into a cleared,
+// L2-resident bitmap instead of a pass over dist[] (256 MB at RMAT-26: 105 us)
+__global__ void bfs_queue_bitmap_kernel(const int32_t* __restrict__ q, int64_t n, unsigned int* __restrict__ bm32) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const int32_t v = q[i];
+        atomicOr(&bm32[v >> 5], 1u << (v & 31));
+    }
+}
+
 // queue of a level straight from dist[] (ballot-aggregated append)
 __global__ void bfs_level_queue_kernel(const int32_t* __restrict__ dist, int64_t V, int32_t level,
                                        int32_t* __restrict__ q, unsigned long long* __restrict__ qcount) {
@@ -475,10 +486,12 @@ extern "C" int gmx_bfs_start(gmx_bfs_t* b, gmx_node_t root) {
     GMX_REQUIRE(b, "bfs is NULL");
     const int64_t V = b->V;
     const bool root_ok = root >= 0 && root < V;
+    // everything on the stream, one synchronisation at the end (three blocking memsets and two staged copies were a
+    // 0.1 ms gap in front of the first level)
     if (V > 0) hipLaunchKernelGGL(bfs_init_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, b->dist.p, V, root_ok ? root : -1);
-    GMX_HIP(hipMemset(b->ctr.p, 0, sizeof(bfs_counters)));
-    GMX_HIP(hipMemset(b->bm[0].p, 0, sizeof(unsigned long long) * (size_t) b->words));
-    GMX_HIP(hipMemset(b->bm[1].p, 0, sizeof(unsigned long long) * (size_t) b->words));
+    GMX_HIP(hipMemsetAsync(b->ctr.p, 0, sizeof(bfs_counters), 0));
+    GMX_HIP(hipMemsetAsync(b->bm[0].p, 0, sizeof(unsigned long long) * (size_t) b->words, 0));
+    GMX_HIP(hipMemsetAsync(b->bm[1].p, 0, sizeof(unsigned long long) * (size_t) b->words, 0));
     b->level = 0;
     b->cur_count = b->reached = root_ok ? 1 : 0;
     b->explored = 0;
@@ -490,12 +503,13 @@ extern "C" int gmx_bfs_start(gmx_bfs_t* b, gmx_node_t root) {
     b->cur_edges = -1;
     b->found_total = 0;
     if (root_ok) {
-        GMX_HIP(hipMemcpy(b->q0.p, &root, sizeof(int32_t), hipMemcpyHostToDevice));
-        int32_t rb[2] = {0, 0};
-        GMX_HIP(hipMemcpy(rb, b->g->begin.p + root, 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
-        b->cur_edges = rb[1] - rb[0];
-    }
-    GMX_HIP(hipDeviceSynchronize());
+        int32_t* h = (int32_t*) b->h_mf;   // (pinned, 8 bytes: root on its way in, then its row bounds on their way out)
+        h[0] = root;
+        GMX_HIP(hipMemcpyAsync(b->q0.p, h, sizeof(int32_t), hipMemcpyHostToDevice, 0));
+        GMX_HIP(hipMemcpyAsync(h, b->g->begin.p + root, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, 0));   // (stream order: after the read of h[0])
+        GMX_HIP(hipStreamSynchronize(0));
+        b->cur_edges = h[1] - h[0];
+    } else GMX_HIP(hipStreamSynchronize(0));
     return GMX_OK;
 }
 
@@ -532,9 +546,15 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
     }
     if (bottom_up) {
         GMX_HIP(hipMemsetAsync(&b->ctr.p->next_count, 0, 2 * sizeof(unsigned long long), 0));   // next_count, next_edges; `edges` keeps accumulating
-        if (!b->frontier_bm_valid)   // first bottom-up level after queue levels: frontier = {v : dist[v] == level}
-            hipLaunchKernelGGL(bfs_level_bitmap_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
-                               (const int32_t*) b->dist.p, V, b->level, b->bm[b->fr].p);
+        if (!b->frontier_bm_valid) {   // first bottom-up level after queue levels: frontier = {v : dist[v] == level}
+            if (!b->frontier_is_bitmap) {   // ... which is the queue the last top-down level wrote
+                GMX_HIP(hipMemsetAsync(b->bm[b->fr].p, 0, sizeof(unsigned long long) * (size_t) b->words, 0));
+                hipLaunchKernelGGL(bfs_queue_bitmap_kernel, dim3(grid_for(b->cur_count, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
+                                   (const int32_t*) b->cur_q, b->cur_count, (unsigned int*) b->bm[b->fr].p);
+            } else
+                hipLaunchKernelGGL(bfs_level_bitmap_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
+                                   (const int32_t*) b->dist.p, V, b->level, b->bm[b->fr].p);
+        }
         const int64_t v_lo = (int64_t) b->rank * b->slice_words * 64;
         const int64_t v_hi = v_lo + b->slice_words * 64;
         hipLaunchKernelGGL(bfs_bottomup_part_kernel, dim3(grid_for(v_hi - v_lo, BFS_THREADS, 256 * 32)), dim3(BFS_THREADS), 0, 0,
