@@ -13,25 +13,30 @@
 //   bin-major    one item per pair: 16-bit bin-local row number + the value slot that phase 1 fills; a cell's items
 //                are contiguous in both orders, a bin's cells follow each other.
 //
-//   phase 1  one workgroup per tile (big tiles are cut into chunks): contribution tile -> LDS (coalesced), then
-//            * pair form  (pr_cold_tile_kernel; tiles whose pairs average >= 1.25 edges -- the hot sources): every wave takes
-//              blocks of 512 edges, a lane 8 consecutive ones (one 16-byte load), gathers from LDS, sums in fp64
-//              along the lane, closes pairs that span lanes with a segmented wave scan (__shfl_up) and stores one
-//              value per pair.  Pairs are cut at block ends at plan time (a longer pair simply becomes several
-//              items of the same row), so a block needs nothing from its neighbours: no fix-up pass.
-//            * edge form  (same kernel, same queue; tiles where almost every pair is a single edge -- the cold tail): every edge is
-//              an item; 8 lanes copy a group with one 8-byte load, four LDS reads and one 16-byte store each, so
-//              every store instruction writes whole aligned 128-byte lines.
+//   phase 1  pr_cold_tile_kernel, persistent, one 1024-thread workgroup per CU, work items (tile, run of groups) from
+//            one queue; an item's tile of contributions is copied into LDS (coalesced), then
+//            * pair form  (tiles whose pairs average >= 1.25 edges -- the hot sources): every wave takes blocks of 512
+//              entries, a lane 8 consecutive ones (one 16-byte load, prefetched by hand-counted inline-asm loads),
+//              gathers from LDS, sums in fp64 along the lane, closes pairs that span lanes with a segmented wave scan
+//              (DPP), stages the pair sums in LDS and stores them as runs of consecutive value slots.  Pairs are cut
+//              at block ends at plan time (a longer pair simply becomes several items of the same row), so a block
+//              needs nothing from its neighbours: no fix-up pass.
+//            * edge form  (same kernel, same queue; tiles where almost every pair is a single edge -- the cold tail):
+//              every edge is an item; 8 lanes copy a group with one 8-byte load, four LDS reads and one 16-byte store
+//              each, so every store instruction writes whole aligned 128-byte lines.
 //            The only metadata is one int per group of 32 edges (slot of the first pair that ends in the group).
 //   phase 2  pr_cold_accum_kernel: one workgroup per bin (hub bins are split into chunks): streams values + 16-bit
 //            row numbers (coalesced) and adds into 64-bit FIXED-POINT accumulators in LDS.  Integer adds commute,
 //            so the result does not depend on the order the lanes arrive in: bit-reproducible without ordering
 //            anything.  fp32 values: one limb, 2^-62 resolution (fp32 keeps 24 bits; the smallest contribution of
 //            an RMAT-26 run is ~2^-34).  fp64 values: two limbs (2^-62 and 2^-(62+lo_bits)), > 100 bits below 1.0.
-//   phase 3  pr_cold_reduce_kernel adds the chunk accumulators of the split bins.
+//            With every in-edge binned the workgroup then applies the PageRank update to its rows itself (FUSE).
+//   phase 3  pr_cold_reduce_kernel / pr_cold_reduce_few_kernel add the chunk accumulators of the split bins.
 //
-// Output: cold[i], the sum over the binned in-neighbours of active row i, element type S, which
-// pr_combine_kernel adds after the per-slice sums of the pull sweep (fixed order).
+// Output: the finished rows (fused form), or cold[i], the sum over the binned in-neighbours of active row i, element
+// type S, which pr_combine_kernel adds after the per-slice sums of the pull sweep (fixed order).
+// The step can be enqueued in parts (pr_cold_set_parts: phase 1 by tile class, phases 2-3 by bin range) for the
+// pipelined multi-GPU step.  What bounds the kernels, and what was tried: DESIGN.md section 4.1.
 // HBM bytes (fp32): 2.125 per edge + 10 per pair (4 written, 4 + 2 read), instead of 4 + a gather per edge.
 #pragma clang fp contract(off)
 
@@ -354,7 +359,7 @@ __device__ __forceinline__ double prc_clear_if(double x, int mask) {
 }
 
 // One block of the pair form: 8 entries of this lane in `cur`, `o` = slot of the first pair that ends in the lane's
-// group.  Written for instruction count (the kernel is VALU-issue bound): pair ends are 0 / -1 masks taken from the
+// group.  Written for instruction count (see DESIGN.md 4.1 for what bounds the kernel): pair ends are 0 / -1 masks taken from the
 // entries by bit-field extracts, nothing branches on them.
 //   pass 1  the lane's open tail (sum behind its last pair end) -> segmented wave scan -> the open sum that enters
 //           the lane (carry);
