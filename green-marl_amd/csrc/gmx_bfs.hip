@@ -22,6 +22,8 @@
 #include <float.h>
 #include <limits.h>
 #include <string.h>
+#include <atomic>
+#include <chrono>
 #include <rocprim/rocprim.hpp>
 
 #define BFS_THREADS 256
@@ -42,10 +44,34 @@ struct bfs_counters {
         unsigned long long pad[14];
     } shard[BFS_SHARDS];
 };
+// A level's totals for the host: summed on the device and written straight into pinned host memory, the level's tag
+// last.  The host spins on the tag -- a stream synchronisation takes ~20 us to wake up, which at small scales was
+// most of a level.
+struct bfs_level_totals {
+    unsigned long long next_count, next_edges, edges, found;
+    volatile unsigned long long tag;
+};
 __device__ __forceinline__ void bfs_count(bfs_counters* __restrict__ ctr, unsigned long long edges, unsigned long long found) {
     const int sh = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (BFS_SHARDS - 1);
     if (edges) atomicAdd(&ctr->shard[sh].edges, edges);
     if (found) atomicAdd(&ctr->shard[sh].found, found);
+}
+__global__ void bfs_totals_kernel(const bfs_counters* __restrict__ ctr, bfs_level_totals* __restrict__ out, unsigned long long tag) {
+    const int lane = threadIdx.x;   // 64 threads, one shard each
+    unsigned long long e = ctr->shard[lane].edges, f = ctr->shard[lane].found;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        e += __shfl_down(e, o, 64);
+        f += __shfl_down(f, o, 64);
+    }
+    if (lane == 0) {
+        out->next_count = ctr->next_count;
+        out->next_edges = ctr->next_edges;
+        out->edges = e;
+        out->found = f;
+        __threadfence_system();
+        out->tag = tag;
+    }
 }
 static void bfs_totals(const bfs_counters& h, unsigned long long* edges, unsigned long long* found) {
     unsigned long long e = 0, f = 0;
@@ -57,9 +83,24 @@ static void bfs_totals(const bfs_counters& h, unsigned long long* edges, unsigne
     *found = f;
 }
 
-__global__ void bfs_init_kernel(int32_t* __restrict__ dist, int64_t V, int32_t root) {
+// everything a traversal starts from, in one launch: dist[], both bitmaps, the counters, the root in the first queue
+// and its out-degree on its way to the host (next_edges of "level -1", tag 0 of the run)
+__global__ void bfs_init_kernel(int32_t* __restrict__ dist, int64_t V, int32_t root, unsigned long long* __restrict__ bm0,
+                                unsigned long long* __restrict__ bm1, int64_t words, bfs_counters* __restrict__ ctr,
+                                int32_t* __restrict__ q0, const int32_t* __restrict__ begin, bfs_level_totals* __restrict__ out,
+                                unsigned long long tag) {
     int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    if (i < (int64_t) (sizeof(bfs_counters) / sizeof(unsigned long long))) ((unsigned long long*) ctr)[i] = 0ull;
+    if (i == 0) {
+        if (root >= 0) q0[0] = root;
+        out->next_count = root >= 0 ? 1 : 0;
+        out->next_edges = root >= 0 ? (unsigned long long) (begin[root + 1] - begin[root]) : 0ull;
+        out->edges = out->found = 0;
+        __threadfence_system();
+        out->tag = tag;
+    }
+    for (int64_t w = i; w < words; w += stride) bm0[w] = bm1[w] = 0ull;
     for (; i < V; i += stride) dist[i] = (i == root) ? 0 : INT_MAX;
 }
 
@@ -350,9 +391,12 @@ struct gmx_bfs {
     // per-level read-backs (frontier size, frontier edges) go through pinned host memory: a level costs two
     // host round trips, and with pageable memory each is a staged copy -- at RMAT-24 that was most of the time
     bfs_counters* h_ctr = nullptr;
+    bfs_level_totals* h_tot = nullptr;   // pinned; written by bfs_totals_kernel
+    unsigned long long tot_tag = 0;
     int64_t* h_mf = nullptr;
     ~gmx_bfs() {
         if (h_ctr) (void) hipHostFree(h_ctr);
+        if (h_tot) (void) hipHostFree(h_tot);
         if (h_mf) (void) hipHostFree(h_mf);
     }
 };
@@ -461,6 +505,12 @@ extern "C" int gmx_bfs_create(gmx_graph_t* g, int rank, int nranks, gmx_bfs_t** 
         delete b;
         return st;
     }
+    if (hipHostMalloc((void**) &b->h_tot, sizeof(bfs_level_totals), hipHostMallocDefault) != hipSuccess) {
+        gmx_set_error("hipHostMalloc failed");
+        delete b;
+        return GMX_ERR_NOMEM;
+    }
+    memset(b->h_tot, 0, sizeof(bfs_level_totals));
     if (hipHostMalloc((void**) &b->h_ctr, sizeof(bfs_counters), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**) &b->h_mf, sizeof(int64_t), hipHostMallocDefault) != hipSuccess) {
         delete b;
@@ -482,16 +532,32 @@ extern "C" int gmx_bfs_free(gmx_bfs_t* b) {
     return GMX_OK;
 }
 
+// spin on the tag of the pinned totals; after ~2 s of nothing fall back to a synchronisation (which also reports a
+// failed kernel)
+static int bfs_wait_totals(gmx_bfs* b, unsigned long long tag) {
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long long spins = 0;
+    while (b->h_tot->tag != tag) {
+        if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            GMX_HIP(hipStreamSynchronize(0));
+            GMX_REQUIRE(b->h_tot->tag == tag, "bfs: the level's totals did not arrive");
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return GMX_OK;
+}
+
 extern "C" int gmx_bfs_start(gmx_bfs_t* b, gmx_node_t root) {
     GMX_REQUIRE(b, "bfs is NULL");
     const int64_t V = b->V;
     const bool root_ok = root >= 0 && root < V;
-    // everything on the stream, one synchronisation at the end (three blocking memsets and two staged copies were a
-    // 0.1 ms gap in front of the first level)
-    if (V > 0) hipLaunchKernelGGL(bfs_init_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, b->dist.p, V, root_ok ? root : -1);
-    GMX_HIP(hipMemsetAsync(b->ctr.p, 0, sizeof(bfs_counters), 0));
-    GMX_HIP(hipMemsetAsync(b->bm[0].p, 0, sizeof(unsigned long long) * (size_t) b->words, 0));
-    GMX_HIP(hipMemsetAsync(b->bm[1].p, 0, sizeof(unsigned long long) * (size_t) b->words, 0));
+    // one launch; the root's out-degree comes back through pinned memory (see bfs_level_totals)
+    const unsigned long long tag = ++b->tot_tag;
+    hipLaunchKernelGGL(bfs_init_kernel, dim3(grid_for(V > (int64_t) (sizeof(bfs_counters) / 8) ? V : (int64_t) (sizeof(bfs_counters) / 8))), dim3(BFS_THREADS), 0, 0,
+                       b->dist.p, V, root_ok ? (int32_t) root : -1, b->bm[0].p, b->bm[1].p, b->words, b->ctr.p, b->q0.p,
+                       (const int32_t*) b->g->begin.p, b->h_tot, tag);
+    GMX_HIP(hipGetLastError());
     b->level = 0;
     b->cur_count = b->reached = root_ok ? 1 : 0;
     b->explored = 0;
@@ -502,14 +568,8 @@ extern "C" int gmx_bfs_start(gmx_bfs_t* b, gmx_node_t root) {
     b->next_q = b->q1.p;
     b->cur_edges = -1;
     b->found_total = 0;
-    if (root_ok) {
-        int32_t* h = (int32_t*) b->h_mf;   // (pinned, 8 bytes: root on its way in, then its row bounds on their way out)
-        h[0] = root;
-        GMX_HIP(hipMemcpyAsync(b->q0.p, h, sizeof(int32_t), hipMemcpyHostToDevice, 0));
-        GMX_HIP(hipMemcpyAsync(h, b->g->begin.p + root, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, 0));   // (stream order: after the read of h[0])
-        GMX_HIP(hipStreamSynchronize(0));
-        b->cur_edges = h[1] - h[0];
-    } else GMX_HIP(hipStreamSynchronize(0));
+    GMX_CHECK(bfs_wait_totals(b, tag));
+    if (root_ok) b->cur_edges = (int64_t) b->h_tot->next_edges;
     return GMX_OK;
 }
 
@@ -626,11 +686,12 @@ extern "C" int gmx_bfs_step_end(gmx_bfs_t* b, int64_t* next_count) {
         b->frontier_is_bitmap = b->frontier_bm_valid = true;
         b->pending_bottom_up = false;
     }
-    GMX_HIP(hipMemcpyAsync(b->h_ctr, b->ctr.p, sizeof(bfs_counters), hipMemcpyDeviceToHost, 0));
-    GMX_HIP(hipStreamSynchronize(0));
-    const bfs_counters& h = *b->h_ctr;
-    unsigned long long edges = 0, found = 0;
-    bfs_totals(h, &edges, &found);
+    const unsigned long long tag = ++b->tot_tag;
+    hipLaunchKernelGGL(bfs_totals_kernel, dim3(1), dim3(64), 0, 0, (const bfs_counters*) b->ctr.p, b->h_tot, tag);
+    GMX_HIP(hipGetLastError());
+    GMX_CHECK(bfs_wait_totals(b, tag));
+    struct { unsigned long long next_count, next_edges; } h = {b->h_tot->next_count, b->h_tot->next_edges};
+    const unsigned long long edges = b->h_tot->edges, found = b->h_tot->found;
     // a top-down level leaves its queue tail in next_count, a bottom-up level its finds in the running total
     b->cur_count = b->cur_edges == -2 ? (int64_t) h.next_count : (int64_t) (found - b->found_total);
     b->found_total = found;

@@ -1,10 +1,13 @@
-# per-launch kernel times of hop_dist RMAT-26 from vertex 0 (development helper; run through gpurun)
+# per-launch kernel times of the last hop_dist traversal of tools/bfs_prof.py (development helper; run through gpurun)
+# usage: bfs_trace.sh [scale]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/bfs26 -- python3 green-marl_amd/tools/bfs_prof.py 26 3 > gpurun_out/bfs26.log 2>&1 || exit 1
-tail -3 gpurun_out/bfs26.log
+sc=${1:-26}
+export BFS_TRACE_DIR=gpurun_out/bfs$sc
+rocprofv3 --kernel-trace --output-format csv -d $BFS_TRACE_DIR -- python3 green-marl_amd/tools/bfs_prof.py $sc 3 > $BFS_TRACE_DIR.log 2>&1 || exit 1
+tail -3 $BFS_TRACE_DIR.log
 python3 - <<'PY'
-import csv, glob
-f = sorted(glob.glob("gpurun_out/bfs26/*/*kernel_trace.csv"))[-1]
+import csv, glob, os
+f = sorted(glob.glob(os.environ["BFS_TRACE_DIR"] + "/*/*kernel_trace.csv"))[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 rows = [r for r in rows if r["Kernel_Name"].startswith("bfs") or "bfs_" in r["Kernel_Name"]]
 # the last traversal: from the last bfs_init_kernel on
