@@ -376,6 +376,8 @@ struct gmx_bfs {
     dbuf<int64_t> off;
     dbuf<char> scan_tmp;
     size_t scan_bytes = 0;
+    dbuf<unsigned long long> cand;    // unvisited vertices with in-edges, kept from one bottom-up level to the next
+    bool cand_valid = false;
     dbuf<unsigned long long> bm[2];   // frontier / found, swapped after every bottom-up level
     int fr = 0;                       // bm[fr] = frontier, bm[1 - fr] = found
     dbuf<bfs_counters> ctr;
@@ -407,7 +409,9 @@ __global__ void __launch_bounds__(BFS_THREADS)
 bfs_bottomup_part_kernel(const int32_t* __restrict__ r_begin, const int32_t* __restrict__ r_node_idx,
                          int64_t v_lo, int64_t v_hi, int64_t V, const uint32_t* __restrict__ frontier_bm,
                          const int32_t* dist, unsigned long long* __restrict__ found_bm,
-                         int32_t* dist_w /* NULL or == dist */, int32_t next_level, bfs_counters* __restrict__ ctr) {
+                         int32_t* dist_w /* NULL or == dist */, int32_t next_level, bfs_counters* __restrict__ ctr,
+                         const unsigned long long* cand_in /* NULL: take the unvisited from dist[] */,
+                         unsigned long long* cand_out) {
     int64_t t = v_lo + (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
     unsigned long long inspected = 0, found_cnt = 0;
@@ -417,10 +421,24 @@ bfs_bottomup_part_kernel(const int32_t* __restrict__ r_begin, const int32_t* __r
         // shorter, and most long ones find a parent at once); what is left of the long rows is then searched by the
         // whole wave, one row at a time, 64 entries per step with an early exit -- a lone lane walking a
         // 10^4-entry row of a vertex that has no parent in this level was the tail of the whole level.
-        bool found = false;
+        // Who still looks for a parent: in the first bottom-up level of a run every vertex with dist == INT_MAX; the
+        // level leaves the ones that found none AND have in-edges as a bitmap (cand), and the following levels read
+        // that -- 8 bytes per 64 vertices instead of their dist[] and r_begin[] entries (RMAT-26: two thirds of the
+        // vertices are out after the first level, and a pass over both arrays is 0.1 ms).
+        bool active;
+        if (cand_in) {
+            const unsigned long long cw = cand_in[t >> 6];
+            if (cw == 0ull) {   // (wave-uniform)
+                if (lane == 0) found_bm[t >> 6] = 0ull;
+                continue;
+            }
+            active = (cw >> lane) & 1ull;
+        } else active = t < V && dist[t] == INT_MAX;
+        bool found = false, has_in = false;
         int32_t rest_b = 0, rest_e = 0;
-        if (t < V && dist[t] == INT_MAX) {
+        if (active) {
             const int32_t b = r_begin[t], e = r_begin[t + 1];
+            has_in = e > b;
             const int32_t own_e = e - b > BFS_BU_OWN ? b + BFS_BU_OWN : e;
             for (int32_t i = b; i < own_e; i++) {
                 const int32_t w = r_node_idx[i];
@@ -454,7 +472,11 @@ bfs_bottomup_part_kernel(const int32_t* __restrict__ r_begin, const int32_t* __r
             if (lane == src) found = hit;
         }
         const unsigned long long m = __ballot(found);
-        if ((threadIdx.x & 63) == 0) found_bm[t >> 6] = m;
+        const unsigned long long still = __ballot(active && has_in && !found);
+        if ((threadIdx.x & 63) == 0) {
+            found_bm[t >> 6] = m;
+            cand_out[t >> 6] = still;
+        }
         // single rank: the whole bitmap is this rank's, so dist[] can be settled right here (dist_w aliases dist;
         // a vertex only ever reads its own entry) and the separate apply pass is not needed
         if (dist_w) {
@@ -501,7 +523,7 @@ extern "C" int gmx_bfs_create(gmx_graph_t* g, int rank, int nranks, gmx_bfs_t** 
     int st = GMX_OK;
     if ((st = b->dist.alloc(V1)) || (st = b->q0.alloc(V1)) || (st = b->q1.alloc(V1)) || (st = b->deg.alloc(V1)) ||
         (st = b->off.alloc(V1 + 2)) || (st = b->ctr.alloc(1)) || (st = b->qcount.alloc(1)) ||
-        (st = b->bm[0].alloc((size_t) b->words)) || (st = b->bm[1].alloc((size_t) b->words))) {
+        (st = b->bm[0].alloc((size_t) b->words)) || (st = b->bm[1].alloc((size_t) b->words)) || (st = b->cand.alloc((size_t) b->words))) {
         delete b;
         return st;
     }
@@ -563,6 +585,7 @@ extern "C" int gmx_bfs_start(gmx_bfs_t* b, gmx_node_t root) {
     b->explored = 0;
     b->edges = 0;
     b->frontier_is_bitmap = b->frontier_bm_valid = b->pending_bottom_up = false;
+    b->cand_valid = false;
     b->fr = 0;
     b->cur_q = b->q0.p;
     b->next_q = b->q1.p;
@@ -619,10 +642,13 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
         const int64_t v_hi = v_lo + b->slice_words * 64;
         hipLaunchKernelGGL(bfs_bottomup_part_kernel, dim3(grid_for(v_hi - v_lo, BFS_THREADS, 256 * 32)), dim3(BFS_THREADS), 0, 0,
                            g->r_begin.p, g->r_node_idx.p, v_lo, v_hi, V, (const uint32_t*) b->bm[b->fr].p,
-                           (const int32_t*) b->dist.p, b->bm[1 - b->fr].p, b->nranks == 1 ? b->dist.p : nullptr, b->level + 1, b->ctr.p);
+                           (const int32_t*) b->dist.p, b->bm[1 - b->fr].p, b->nranks == 1 ? b->dist.p : nullptr, b->level + 1, b->ctr.p,
+                           b->cand_valid ? (const unsigned long long*) b->cand.p : nullptr, b->cand.p);
+        b->cand_valid = true;
         b->pending_bottom_up = true;
         *needs_exchange = b->nranks > 1 ? 1 : 0;
     } else {
+        b->cand_valid = false;         // a top-down level visits vertices the candidate bitmap would still hold
         if (b->frontier_is_bitmap) {   // back from bottom-up: rebuild the queue and its edge offsets
             GMX_HIP(hipMemsetAsync(b->qcount.p, 0, sizeof(unsigned long long), 0));
             if (b->frontier_bm_valid)   // the frontier is the bitmap the last bottom-up level found
