@@ -213,6 +213,36 @@ def test_hop_dist_vs_oracle_larger(gmx, scale, permute):
     g.free()
 
 
+def test_hop_dist_direction_switches_twice(gmx):
+    """Two dense clusters joined by a long path: from a vertex of the first the traversal goes top-down, bottom-up
+    (the cluster floods), top-down again along the path, and bottom-up a second time in the far cluster -- the
+    candidate bitmap the bottom-up levels hand each other has to be rebuilt after the top-down levels in between.
+    Also as N rank states side by side (bitmap slices exchanged by device copies)."""
+    rng = np.random.default_rng(7)
+    nc, npath = 6000, 60
+    V = 2 * nc + npath
+    src, dst = [], []
+    for base in (0, nc + npath):
+        a = rng.integers(0, nc, 24 * nc) + base
+        b = rng.integers(0, nc, 24 * nc) + base
+        src += [a, b]
+        dst += [b, a]
+    path = np.arange(nc - 1, nc + npath + 1)          # last vertex of cluster one ... first vertex of cluster two
+    src += [path[:-1], path[1:]]
+    dst += [path[1:], path[:-1]]
+    og = po.graph_from_edges(V, np.concatenate(src).astype(np.int32), np.concatenate(dst).astype(np.int32))
+    want = po.bfs_queue(og, 0)
+    assert (want != INT_MAX).sum() > 0.95 * V and want.max() > npath       # both clusters reached, through the path
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    dist, st = g.hop_dist(0)
+    assert np.array_equal(dist, want)
+    g.free()
+    for nranks in (2, 3):
+        got, levels, exchanges = _bfs_ranks_in_one_process(gmx, og, 0, nranks)
+        assert all(np.array_equal(d, want) for d in got)
+        assert exchanges >= 3                           # bottom-up levels (one exchange each) in BOTH clusters
+
+
 def test_hop_dist_bad_root(gmx, golden):
     c = golden["cases"]["rmat6_noperm"]
     g = gmx.Graph.upload(c["begin"], c["node_idx"], c["r_begin"], c["r_node_idx"])
