@@ -69,6 +69,12 @@ struct gmx_pr_multi {
     std::vector<hipStream_t> stream;
     std::vector<hipEvent_t> done;
     std::vector<rccl_comm_t> comm;
+    // pipelined peer exchange (two row chunks; see gmx_pr_multi_run): copy streams and "landed" events per
+    // (sender, receiver, chunk), "computed" events per (rank, chunk)
+    bool pipelined = false;
+    std::vector<hipStream_t> cstream;     // [(r * nranks + q) * 2 + c]
+    std::vector<hipEvent_t> landed;       // same index
+    std::vector<hipEvent_t> computed;     // [r * 2 + c]
     int home = 0;                         // device the caller's graph lives on
     ~gmx_pr_multi() {
         for (size_t r = 0; r < pr.size(); r++) {
@@ -76,6 +82,17 @@ struct gmx_pr_multi {
             if (pr[r]) gmx_pr_free(pr[r]);
             if (r < stream.size() && stream[r]) (void) hipStreamDestroy(stream[r]);
             if (r < done.size() && done[r]) (void) hipEventDestroy(done[r]);
+            for (size_t q = 0; q < pr.size() && !cstream.empty(); q++)
+                for (int c = 0; c < 2; c++) {
+                    const size_t i = (r * pr.size() + q) * 2 + c;
+                    if (cstream[i]) {
+                        (void) hipStreamSynchronize(cstream[i]);
+                        (void) hipStreamDestroy(cstream[i]);
+                    }
+                    if (landed[i]) (void) hipEventDestroy(landed[i]);
+                }
+            for (int c = 0; c < 2 && !computed.empty(); c++)
+                if (computed[r * 2 + c]) (void) hipEventDestroy(computed[r * 2 + c]);
         }
         for (rccl_comm_t c : comm)
             if (c && g_rccl.CommDestroy) (void) g_rccl.CommDestroy(c);
@@ -186,6 +203,46 @@ int gmx_pr_multi_create(gmx_graph* g, int elem, int nranks, gmx_pr_multi** out) 
                 hipEventCreateWithFlags(&m->done[r], hipEventDisableTiming) != hipSuccess) { gmx_set_error("stream/event creation failed"); st = GMX_ERR_HIP; break; }
         }
         if (st) break;
+        // Peer copies + every in-edge binned: with GMX_PR_MULTI_PIPELINE=1 the step is cut in two row chunks and
+        // pipelined (see pipelined_iteration).  Off by default: ONE host thread then issues ~480 HIP calls per
+        // iteration for 8 ranks (16 launches, 112 copies on streams of their own, their events and waits) against ~130
+        // for the step in one piece, and at ~5 us a call that is longer than the 0.4 ms the ranks compute -- measured
+        // with 8 rank states on one GPU (RMAT-24, 50 iterations): 567 ms pipelined, 380 ms in one piece.  The
+        // one-process-per-GPU driver (dist_pagerank.py) issues ~30 calls per rank and iteration and pipelines by default.
+        if (m->exchange == EX_PEER && nranks > 1 && env_int("GMX_PR_MULTI_PIPELINE", 0) != 0) {
+            bool ok = true;
+            for (int r = 0; r < nranks && ok; r++) {
+                int classes = 0, chunks = 0;
+                if (hipSetDevice(m->dev[r]) != hipSuccess) { ok = false; break; }
+                ok = gmx_pr_gather_classes(m->pr[r], &classes) == GMX_OK && classes == 2 && gmx_pr_set_chunks(m->pr[r], 2) == GMX_OK &&
+                     gmx_pr_num_chunks(m->pr[r], &chunks) == GMX_OK && chunks == 2;
+            }
+            if (ok) {
+                m->cstream.assign((size_t) nranks * nranks * 2, nullptr);
+                m->landed.assign((size_t) nranks * nranks * 2, nullptr);
+                m->computed.assign((size_t) nranks * 2, nullptr);
+                for (int r = 0; r < nranks && st == GMX_OK; r++) {
+                    if (hipSetDevice(m->dev[r]) != hipSuccess) { gmx_set_error("hipSetDevice(%d) failed", m->dev[r]); st = GMX_ERR_HIP; break; }
+                    for (int c = 0; c < 2 && st == GMX_OK; c++) {
+                        if (hipEventCreateWithFlags(&m->computed[(size_t) r * 2 + c], hipEventDisableTiming) != hipSuccess) st = GMX_ERR_HIP;
+                        for (int q = 0; q < nranks && st == GMX_OK; q++) {
+                            if (q == r) continue;
+                            const size_t i = ((size_t) r * nranks + q) * 2 + c;
+                            if (hipStreamCreateWithFlags(&m->cstream[i], hipStreamNonBlocking) != hipSuccess ||
+                                hipEventCreateWithFlags(&m->landed[i], hipEventDisableTiming) != hipSuccess) st = GMX_ERR_HIP;
+                        }
+                    }
+                    if (st) gmx_set_error("stream/event creation failed");
+                }
+                if (st) break;
+                m->pipelined = true;
+            } else {
+                for (int r = 0; r < nranks; r++) {   // back to one piece
+                    (void) hipSetDevice(m->dev[r]);
+                    (void) gmx_pr_set_chunks(m->pr[r], 1);
+                }
+            }
+        }
         if (m->exchange != EX_PEER) {
             if (!g_rccl.load()) { gmx_set_error("GMX_EXCHANGE: librccl.so could not be loaded (%s)", dlerror()); st = GMX_ERR_STATE; break; }
             m->comm.assign((size_t) nranks, nullptr);
@@ -253,6 +310,61 @@ static int exchange(gmx_pr_multi* m) {
 }
 
 // do { sweep; exchange; diff } while (diff > e && cnt < max)   (pagerank.gm:9-19), then the ranks of every rank's rows
+// One pipelined iteration of all ranks (peer copies, two row chunks; the order of DistPageRank._step_pipelined with
+// events in place of barriers -- one host thread sees every stream):
+//   gather(0)  phase 1 over the hub tiles     after the peers' HUB chunks of the previous iteration have landed
+//   gather(1)  phase 1 over the other tiles   after their TAIL chunks have landed too
+//   chunk 0    tail bins -> tail copies to every peer (copy streams of their own), chunk 1  hub bins -> hub copies
+// so the long tail copies run under the hub bins of this iteration and the hub tiles of the next one.  A replica is
+// written by a peer only after events that follow the owner's last read of it (two buffers, as in the Python driver).
+static int pipelined_iteration(gmx_pr_multi* m, bool first) {
+    const int N = m->nranks;
+    const size_t es = (size_t) m->elem;
+    std::vector<char*> next((size_t) N, nullptr);
+    int64_t slice = 0;
+    for (int r = 0; r < N; r++) {
+        void* p = nullptr;
+        int64_t n = 0;
+        GMX_HIP(hipSetDevice(m->dev[r]));
+        GMX_CHECK(gmx_pr_contrib_next_full(m->pr[r], &p, &n));
+        next[(size_t) r] = (char*) p;
+        GMX_CHECK(gmx_pr_contrib_slice(m->pr[r], &p, &slice));
+    }
+    auto idx = [&](int r, int q, int c) { return ((size_t) r * N + q) * 2 + c; };
+    for (int cls = 0; cls < 2; cls++)
+        for (int r = 0; r < N; r++) {
+            GMX_HIP(hipSetDevice(m->dev[r]));
+            if (!first)   // (the first iteration reads what exchange() delivered, already ordered on the compute streams)
+                for (int q = 0; q < N; q++)
+                    if (q != r) GMX_HIP(hipStreamWaitEvent(m->stream[r], m->landed[idx(q, r, cls == 0 ? 1 : 0)], 0));
+            GMX_CHECK(gmx_pr_step_gather(m->pr[r], cls, m->stream[r]));
+        }
+    for (int c = 0; c < 2; c++)
+        for (int r = 0; r < N; r++) {
+            GMX_HIP(hipSetDevice(m->dev[r]));
+            GMX_CHECK(gmx_pr_step_chunk(m->pr[r], c, m->stream[r]));
+            GMX_HIP(hipEventRecord(m->computed[(size_t) r * 2 + c], m->stream[r]));
+            int64_t off = 0, cnt = 0;
+            GMX_CHECK(gmx_pr_chunk_range(m->pr[r], c, &off, &cnt));
+            for (int i = 1; i < N; i++) {
+                const int q = (r + i) % N;   // every rank starts with a different peer
+                const size_t at = ((size_t) r * (size_t) slice + (size_t) off) * es;
+                GMX_HIP(hipStreamWaitEvent(m->cstream[idx(r, q, c)], m->computed[(size_t) r * 2 + c], 0));
+                if (cnt > 0)
+                    GMX_HIP(hipMemcpyPeerAsync(next[(size_t) q] + at, m->dev[q], next[(size_t) r] + at, m->dev[r], (size_t) cnt * es, m->cstream[idx(r, q, c)]));
+                GMX_HIP(hipEventRecord(m->landed[idx(r, q, c)], m->cstream[idx(r, q, c)]));
+            }
+        }
+    return GMX_OK;
+}
+
+// every copy of the pipelined exchange has landed (before the ranks are read back, reset or freed)
+static int pipelined_drain(gmx_pr_multi* m) {
+    for (size_t i = 0; i < m->cstream.size(); i++)
+        if (m->cstream[i]) GMX_HIP(hipStreamSynchronize(m->cstream[i]));
+    return GMX_OK;
+}
+
 int gmx_pr_multi_run(gmx_pr_multi* m, double e, double d, int32_t max_iter, void* rank_host, gmx_stats_t* stats) {
     double diff = 0.0;
     int32_t cnt = 0;
@@ -270,11 +382,15 @@ int gmx_pr_multi_run(gmx_pr_multi* m, double e, double d, int32_t max_iter, void
         GMX_HIP(hipSetDevice(m->dev[0]));
         (void) hipEventRecord(ev0, m->stream[0]);
         do {
-            for (int r = 0; r < m->nranks && st == GMX_OK; r++) {
-                if (hipSetDevice(m->dev[r]) != hipSuccess) { gmx_set_error("hipSetDevice failed"); st = GMX_ERR_HIP; break; }
-                st = gmx_pr_step(m->pr[r], m->stream[r]);
+            if (m->pipelined) {
+                if ((st = pipelined_iteration(m, cnt == 0))) break;
+            } else {
+                for (int r = 0; r < m->nranks && st == GMX_OK; r++) {
+                    if (hipSetDevice(m->dev[r]) != hipSuccess) { gmx_set_error("hipSetDevice failed"); st = GMX_ERR_HIP; break; }
+                    st = gmx_pr_step(m->pr[r], m->stream[r]);
+                }
+                if (st || (st = exchange(m))) break;
             }
-            if (st || (st = exchange(m))) break;
             diff = 0.0;
             for (int r = 0; r < m->nranks && st == GMX_OK; r++) {   // rank order: a fixed sum
                 double dr = 0.0;
@@ -285,6 +401,10 @@ int gmx_pr_multi_run(gmx_pr_multi* m, double e, double d, int32_t max_iter, void
             if (st) break;
             cnt++;
         } while ((diff > e) && (cnt < max_iter));
+        if (m->pipelined) {
+            const int st2 = pipelined_drain(m);
+            if (st == GMX_OK) st = st2;
+        }
         if (st) break;
         GMX_HIP(hipSetDevice(m->dev[0]));
         (void) hipEventRecord(ev1, m->stream[0]);

@@ -381,12 +381,15 @@ def test_pagerank_row_chunked_steps(gmx, scale, nranks, chunks, elem):
     g.free()
 
 
-@pytest.mark.parametrize("scale,ranks,exchange", [(15, 3, "peer"), (18, 2, "peer"), (21, 4, "peer"), (16, 1, "allgather"), (16, 1, "allreduce")])
+@pytest.mark.parametrize("scale,ranks,exchange", [(15, 3, "peer"), (18, 2, "peer"), (21, 4, "peer"), (21, 2, "peer"), (22, 8, "peer"),
+                                                  (16, 1, "allgather"), (16, 1, "allreduce")])
 def test_pagerank_entry_drives_several_ranks_from_one_thread(gmx, scale, ranks, exchange, monkeypatch):
     """gmx_pagerank_f64 / _f32 over N rank states from one host thread (gmx_pr_multi.hip: per-rank streams, peer
     copies behind every sweep, events as the barrier, diff summed in rank order).  The box has one GPU, so the ranks
     share it (GMX_PR_RANKS); the RCCL forms of the exchange need one rank per device and are run with a single rank
-    (library loading, communicator, group calls).  Results: the oracle's, iteration count included."""
+    (library loading, communicator, group calls).  Results: the oracle's, iteration count included.  From 2^21
+    vertices on every in-edge is binned and the peer form can run pipelined (GMX_PR_MULTI_PIPELINE=1: two row chunks,
+    the tail chunk's copies under the next iteration's hub tiles, events as barriers): the same bits."""
     og = po.rmat_graph(scale, permute=True) if scale <= 18 else None
     if og is None:
         g = gmx.Graph.rmat(1 << scale, 16 << scale, 1997, 0.57, 0.19, 0.19, True)
@@ -403,6 +406,12 @@ def test_pagerank_entry_drives_several_ranks_from_one_thread(gmx, scale, ranks, 
         assert rel_err(rank, want) < tol
         rank2, st2 = g.pagerank(0.001, 0.85, 100, dt)          # the cached plan, and run-to-run identical
         assert np.array_equal(rank, rank2) and st2["last_diff"] == st["last_diff"]
+    if scale >= 21 and exchange == "peer":
+        piped = gmx.Graph.upload(*g.download())                # (a fresh device graph: no cached multi-rank plan)
+        monkeypatch.setenv("GMX_PR_MULTI_PIPELINE", "1")
+        rank3, st3 = piped.pagerank(0.001, 0.85, 100, np.float32)
+        assert np.array_equal(rank3, rank2) and st3["iterations"] == st2["iterations"]
+        piped.free()
     g.free()
 
 
