@@ -1992,9 +1992,9 @@ extern "C" int gmx_pr_kernel_time(gmx_pr_t* p, int32_t* launches, double* mean_m
 extern "C" const char* gmx_pr_kernel_name(gmx_pr_t* p) {
     if (!p) return "";
     if (p->ns > 0 && p->cold && p->Eh == 0)
-        return "pr_cold_tile_kernel+pr_cold_accum_kernel+pr_cold_reduce_kernel+pr_diff_reduce2_kernel (+pr_combine_kernel when a step is enqueued in row chunks)";
+        return "pr_cold_tile_kernel+pr_cold_accum_kernel+pr_cold_reduce_few_kernel+pr_cold_reduce_kernel+pr_diff_reduce2_kernel";
     if (p->ns > 0 && p->cold)
-        return "pr_cold_tile_kernel+pr_cold_accum_kernel+pr_cold_reduce_kernel+pr_wave_sliced_kernel+pr_sliced_fixup_kernel+pr_combine_kernel+pr_diff_reduce_kernel";
+        return "pr_cold_tile_kernel+pr_cold_accum_kernel+pr_cold_reduce_few_kernel+pr_cold_reduce_kernel+pr_wave_sliced_kernel+pr_sliced_fixup_kernel+pr_combine_kernel+pr_diff_reduce_kernel";
     if (p->ns > 0) return "pr_wave_sliced_kernel+pr_sliced_fixup_kernel+pr_combine_kernel+pr_diff_reduce_kernel";
     return "pr_wave_kernel+pr_fixup_kernel+pr_diff_reduce_kernel";
 }
