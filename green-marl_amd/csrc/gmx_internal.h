@@ -90,6 +90,9 @@ struct gmx_graph {
     // hop_dist: the single-rank traversal state (queues, bitmaps, dist[]) of the whole-kernel entry, kept for the
     // next call on the same graph instead of nine allocations per call
     gmx_bfs* bfs_cache = nullptr;
+    // bottom-up BFS: per vertex the in-neighbour to try first (the one with most out-edges among the first of its
+    // in-row; -1: no in-edges).  Graph preprocessing like the reverse CSR, built with the first traversal object.
+    dbuf<int32_t> bfs_hint;
 };
 
 // ---- graph construction helpers (gmx_graph.hip) ----
