@@ -231,22 +231,37 @@ def main():
     # The pipelined pushed step has never run on real multi-GPU hardware from the development boxes (one GPU each): if
     # its warm-up fails on some rank, or the replicas are not what an all-gather delivers after the timed steps, every
     # rank drops to the plain pushed step (exchange exposed) and the measurement is repeated.
+    def fail(msg):
+        """A run whose ranks disagree is not a measurement: no metric line, non-zero exit on every rank."""
+        print("bench.py rank %d: %s" % (rank, msg), file=sys.stderr, flush=True)
+        sys.exit(1)
+
+    fell_back = False
     ok = all_agree(warm())
     if not ok and world > 1:
+        fell_back = True
         pr._early_group = None
         pr.reset(0.85)
-        warm()
+        if not all_agree(warm()):
+            fail("the warm-up steps failed again after the fallback to the plain pushed step")
+    elif not ok:
+        fail("the warm-up steps failed")
     dt, launches, kernel_ms = timed()
     last_diff = pr.diff()
     verdict = check_exchange()
     if verdict is False and pr._early_group is not None:
+        fell_back = True
         pr._early_group = None
         pr.reset(0.85)
-        warm()
+        if not all_agree(warm()):
+            fail("the warm-up steps failed after the fallback to the plain pushed step")
         dt, launches, kernel_ms = timed()
         last_diff = pr.diff()
         verdict = check_exchange()
-    exchange_check = None if verdict is None else ("replicas equal an all-gather of the owned slices on every rank" if verdict else "MISMATCH")
+    if verdict is False:
+        fail("exchange check failed: after the timed steps some rank's replica is not what an all-gather of the owned "
+             "slices delivers; no metric is reported")
+    exchange_check = None if verdict is None else "replicas equal an all-gather of the owned slices on every rank"
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -296,6 +311,9 @@ def main():
                                     if pr.exchange == "push" else "RCCL all-gather of contribution slices, %d row chunk(s)") % chunks
                                    + ("; pipelined: the tail chunk travels under the next step's gather over the hub tiles" if pipelined else ""),
                        "exchange_check": exchange_check,
+                       "step_form": "single rank" if world == 1 and not force_coll else
+                                    (("pushed, pipelined" if pipelined else "pushed, plain") if pr.exchange == "push" else "collective")
+                                    + (" (fell back from the pipelined form)" if fell_back else ""),
                        "options": options, "setup_s": round(setup_s, 2), "last_diff": last_diff},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

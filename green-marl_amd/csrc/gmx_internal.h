@@ -80,9 +80,10 @@ struct gmx_graph {
     int device = 0;
     // PageRank plans built by the whole-kernel entries (fp32, fp64), kept for the next call on the same
     // graph: the plan is graph preprocessing, like the reverse CSR.  Freed with the graph.
-    gmx_pr* pr_cache[2] = {nullptr, nullptr};
+    gmx_pr* pr_cache[4] = {nullptr, nullptr, nullptr, nullptr};   // [2], [3]: the pull-sweep plans used for d outside (0, 1]
     // the same for the multi-GPU form of those entries (gmx_pr_multi.hip): N rank states driven by one host thread
     struct gmx_pr_multi* pr_multi_cache[2] = {nullptr, nullptr};
+    bool pr_multi_refused = false;   // the multi-GPU exchange failed its first-contact check on this box: single GPU from then on
     // triangle counting: -1 not examined, 0 general graph, 1 symmetric and simple -> `tc_oriented` holds the
     // forward CSR of the same graph renumbered by ascending degree (its reverse CSR is the same arrays)
     int tc_sym_state = -1;
@@ -119,6 +120,7 @@ struct pr_cold_params {
     int64_t row_lo;  // first owned row (internal numbering)
     int64_t nactive; // owned rows with in-edges
     const int32_t* index_of_row;   // [rows] local row -> position in the active-row list (device)
+    const int32_t* deg_by_id;      // [nranks * slice] out-degree by internal id (device; padding ids < 0), or NULL
 };
 // keys[Ec]: (row << 32 | source) of the cold in-edges of the owned rows, any order (device).
 int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, hipStream_t s, pr_cold** out);
@@ -142,6 +144,9 @@ int pr_cold_gather(pr_cold* c, const void* contrib, int cls, hipStream_t s);
 int pr_cold_accumulate(pr_cold* c, const pr_cold_fuse* fuse, int part, hipStream_t s);
 const double* pr_cold_diff_partials(const pr_cold* c, int64_t* n);
 bool pr_cold_covers_all_rows(const pr_cold* c);
+// fp32 plans keep ONE 2^-62 fixed-point limb: true if that provably holds the 1e-6 bar for damping d on a graph of N
+// vertices (see pr_cold_limb_guard in gmx_pr_cold.hip); fp64 plans (two limbs): always true
+bool pr_cold_limb_guard(const pr_cold* c, double d, double N);
 const void* pr_cold_partial(const pr_cold* c);   // [nactive] x elem, indexed like the per-slice partial sums
 int64_t pr_cold_edges(const pr_cold* c);
 int64_t pr_cold_items(const pr_cold* c);
@@ -152,6 +157,7 @@ int gmx_pr_multi_ranks(const gmx_graph* g);    // ranks the entry uses for this 
 int gmx_pr_multi_create(gmx_graph* g, int elem, int nranks, gmx_pr_multi** out);
 int gmx_pr_multi_run(gmx_pr_multi* m, double e, double d, int32_t max_iter, void* rank_host, gmx_stats_t* stats);
 void gmx_pr_multi_free(gmx_pr_multi* m);
+bool gmx_pr_multi_verified(const gmx_pr_multi* m);   // false: the first exchange has not passed its check
 
 static inline int gmx_bits_for(int64_t v) {  // bits needed to represent values in [0, v)
     int b = 1;

@@ -220,6 +220,13 @@ __global__ void pr_owned_kernel(const int32_t* __restrict__ perm, const int32_t*
     }
 }
 
+// out-degree by internal id (all ranks' ranges; padding ids keep the -1 they were initialised with)
+__global__ void pr_deg_by_id_kernel(const int32_t* __restrict__ perm, const int32_t* __restrict__ begin, int64_t V, int32_t* __restrict__ deg) {
+    int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; v < V; v += stride) deg[perm[v]] = begin[v + 1] - begin[v];
+}
+
 // local CSR of the owned rows out of the globally sorted keys (row' << 32 | src')
 __global__ void pr_local_csr_kernel(const uint64_t* __restrict__ keys, int64_t E, int64_t row_lo, int64_t rows,
                                     int64_t k_lo, int64_t El, int32_t* __restrict__ rb, int32_t* __restrict__ ridx) {
@@ -1373,7 +1380,11 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                     if (hipStreamSynchronize(s) != hipSuccess) { gmx_set_error("pr plan: active-row renaming failed"); st = GMX_ERR_HIP; break; }
                 }
                 if (p->cold_T >= 0) {   // tile- and bin-major streams of the binned edges
-                    pr_cold_params cp{elem_bytes, nranks, p->slice, p->cold_T, p->row_lo, p->sl_nactive, index_of_row.p};
+                    dbuf<int32_t> deg_by_id;
+                    if ((st = deg_by_id.alloc((size_t) p->Vpad))) break;
+                    if (hipMemsetAsync(deg_by_id.p, 0xff, sizeof(int32_t) * (size_t) p->Vpad, s) != hipSuccess) { gmx_set_error("pr plan: memset failed"); st = GMX_ERR_HIP; break; }
+                    hipLaunchKernelGGL(pr_deg_by_id_kernel, dim3(grid_for(V)), dim3(256), 0, s, (const int32_t*) perm.p, g->begin.p, V, deg_by_id.p);
+                    pr_cold_params cp{elem_bytes, nranks, p->slice, p->cold_T, p->row_lo, p->sl_nactive, index_of_row.p, deg_by_id.p};
                     if ((st = pr_cold_create(cold_keys, Ec, cp, s, &p->cold))) break;
                 }
                 int64_t nblk_s[PR_MAX_SLICES], blk_off[PR_MAX_SLICES + 1];
@@ -1457,6 +1468,16 @@ extern "C" int gmx_pr_free(gmx_pr_t* p) {
 
 extern "C" int gmx_pr_reset(gmx_pr_t* p, double d) {
     GMX_REQUIRE(p, "pr is NULL");
+    if (p->cold) {
+        // the binned sweep adds in 2^-62 fixed point: contributions must stay in [0, 1], which the iteration keeps for
+        // 0 < d <= 1 (ranks >= 0, their sum <= 1) and nothing keeps outside (the reference accepts any d > 0,
+        // pagerank_main.cc:59-62: the whole-kernel entries run those on the pull sweep, which sums in floating point)
+        GMX_REQUIRE(d > 0.0 && d <= 1.0, "damping factor %g outside (0, 1]: not representable by the binned sweep (plan without GMX_PR_COLD_PB)", d);
+        if (!pr_cold_limb_guard(p->cold, d, (double) p->V)) {
+            gmx_set_error("fp32 binned sweep: one 2^-62 limb cannot guarantee 1e-6 for d = %g on this graph (use the fp64 plan)", d);
+            return GMX_ERR_STATE;
+        }
+    }
     p->d = d;
     p->cnt = 0;
     p->cur = 0;
@@ -2024,17 +2045,36 @@ static int pagerank_entry(gmx_graph_t* g, double e, double d, int32_t max_iter, 
     if (g->V == 0) return GMX_OK;
     // several GPUs (or GMX_PR_RANKS > 1): one host thread drives N rank states (gmx_pr_multi.hip); the plan is cached
     // on the graph like the single-GPU one
-    const int nranks = gmx_pr_multi_ranks(g);
+    // d outside (0, 1] (accepted by the reference driver, pagerank_main.cc:59-62): contributions leave [0, 1], so the
+    // fixed-point bins are out; the pull sweep sums in floating point
+    const bool plain_d = d > 0.0 && d <= 1.0;
+    const int nranks = (g->pr_multi_refused || !plain_d) ? 1 : gmx_pr_multi_ranks(g);
     const char* ex = getenv("GMX_EXCHANGE");
-    if (nranks > 1 || (ex && *ex && strcmp(ex, "peer") != 0)) {   // (an RCCL exchange can be asked for with one rank too)
+    if (!g->pr_multi_refused && plain_d && (nranks > 1 || (ex && *ex && strcmp(ex, "peer") != 0))) {   // (an RCCL exchange can be asked for with one rank too)
         gmx_pr_multi*& mc = g->pr_multi_cache[sizeof(S) == 4 ? 0 : 1];
         if (mc == nullptr) GMX_CHECK(gmx_pr_multi_create(g, (int) sizeof(S), nranks, &mc));
-        return gmx_pr_multi_run(mc, e, d, max_iter, (void*) rank_host, stats);
+        const int mst = gmx_pr_multi_run(mc, e, d, max_iter, (void*) rank_host, stats);
+        if (mst == GMX_OK || gmx_pr_multi_verified(mc)) return mst;
+        // first contact failed (the replicas are not what the owners hold): say so and compute on one device
+        fprintf(stderr, "gmx: %s -- falling back to the single-GPU pagerank\n", gmx_last_error());
+        gmx_pr_multi_free(mc);
+        mc = nullptr;
+        g->pr_multi_refused = true;
+        GMX_HIP(hipSetDevice(g->device));
     }
-    gmx_pr_t*& cached = g->pr_cache[sizeof(S) == 4 ? 0 : 1];
-    if (cached == nullptr) GMX_CHECK(gmx_pr_create(g, (int) sizeof(S), 0, 1, gmx_pr_default_options(g->V, 1), &cached));
+    gmx_pr_t*& cached = g->pr_cache[(sizeof(S) == 4 ? 0 : 1) + (plain_d ? 0 : 2)];
+    if (cached == nullptr)
+        GMX_CHECK(gmx_pr_create(g, (int) sizeof(S), 0, 1, gmx_pr_default_options(g->V, 1) & ~(plain_d ? 0u : (uint32_t) GMX_PR_COLD_PB), &cached));
     gmx_pr_t* p = cached;
     int st = gmx_pr_reset(p, d);
+    if (st == GMX_ERR_STATE && sizeof(S) == 4) {
+        // the fp32 plan's single fixed-point limb cannot hold the bar here (pr_cold_limb_guard): compute with the
+        // two-limb fp64 plan and round once per vertex
+        std::vector<double> tmp((size_t) g->V);
+        GMX_CHECK(pagerank_entry<double>(g, e, d, max_iter, tmp.data(), stats));
+        for (int64_t i = 0; i < g->V; i++) rank_host[i] = (S) tmp[(size_t) i];
+        return GMX_OK;
+    }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double diff = 0.0;
     int32_t cnt = 0;

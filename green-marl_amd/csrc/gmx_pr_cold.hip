@@ -105,6 +105,7 @@ struct pr_cold {
     dbuf<double> diffp;                 // fused finish: [n2] partials of phase 2, then [n3 * binrows / 64] of phase 3
     int grid = 256;
     bool all_bins = false;   // every bin has items (the fused finish reaches every active row)
+    std::vector<int32_t> tile_maxdeg;   // [ntiles] largest out-degree among a tile's sources (host; empty: unknown)
 };
 
 static int prc_grid_for(int64_t n, int block = 256) {
@@ -295,6 +296,38 @@ __global__ void prc_bin_table_kernel(const uint32_t* __restrict__ key2s, const i
             if ((int64_t) (key2s[mid] >> tilebits) < t) lo = mid + 1; else hi = mid;
         }
         table[t] = lo < ncells ? c2s[lo] : (int32_t) ngroups;
+    }
+}
+
+// GMX_PR_DEBUG=2: how long the (tile, row) pairs are.  len[p] += 1 per edge of pair p, then log2 buckets weighted by edges.
+__global__ void prc_dbg_pair_len_kernel(const int32_t* __restrict__ pairidx, int64_t n, int32_t* __restrict__ len) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) atomicAdd(&len[pairidx[i]], 1);
+}
+__global__ void prc_dbg_len_hist_kernel(const int32_t* __restrict__ len, int64_t np, unsigned long long* __restrict__ hist) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < np; i += stride) {
+        const int l = len[i];
+        if (l <= 0) continue;
+        const int b = 32 - __clz(l - 1 > 0 ? l - 1 : 0);   // 1 -> 0, 2 -> 1, 3-4 -> 2, 5-8 -> 3, ...
+        atomicAdd(&hist[2 * (b < 15 ? b : 15)], 1ull);
+        atomicAdd(&hist[2 * (b < 15 ? b : 15) + 1], (unsigned long long) l);
+    }
+}
+
+// largest out-degree among the sources of every tile (the limb guard's input)
+__global__ void prc_tile_maxdeg_kernel(const int32_t* __restrict__ deg, int64_t nids, int64_t slice, int64_t T, int tile_src,
+                                       int32_t* __restrict__ tmax) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    const int64_t span = slice - T;
+    for (; i < nids; i += stride) {
+        const int64_t l = i % slice;
+        const int32_t dg = deg[i];
+        if (l < T || dg <= 0) continue;
+        atomicMax(&tmax[((i / slice) * span + (l - T)) / tile_src], dg);
     }
 }
 
@@ -545,12 +578,12 @@ __device__ __forceinline__ void prc_pair_item(const prc_item1 d, const S* __rest
         PRC_SET_WAIT(A, 40);
         PRC_PROCESS(A);
     }
-    if (k < nsuper) {   // one super-step left, in B; nothing younger than the stores of the previous one
-        PRC_SET_WAIT(B, 32);
-        PRC_PROCESS(B);
-    } else {
-        PRC_SET_WAIT(B, 0);   // the redundant prefetch of the last super-step: land before B is loaded again
-    }
+    // B holds the last super-step (k < nsuper) or a redundant copy of it; either way exactly the 32 stores of the set
+    // processed last are younger than its loads.  ONE wait in front of the branch: with a wait per arm the register
+    // allocator copied B's registers in front of the arm's wait, i.e. read registers whose load was in flight (harmless
+    // there -- the arm never used them -- but exactly what tools/isa_check.py exists to refuse).
+    PRC_SET_WAIT(B, 32);
+    if (k < nsuper) PRC_PROCESS(B);
 #undef PRC_PROCESS
 }
 
@@ -608,7 +641,7 @@ pr_cold_tile_kernel(const prc_item1* __restrict__ items, int n_items, unsigned i
         if (tid == 0) s_item = (int) (atomicAdd(&queue[PRC_Q1P], 1u) - qbase);
         __syncthreads();
         const int it = s_item;
-        if (it >= n_items) break;
+        if ((unsigned) it >= (unsigned) n_items) break;   // (unsigned: a counter that ran away from the host's copy ends the kernel)
         const prc_item1 d = items[it];
         if (d.tile != loaded) {   // (workgroup-uniform) chunks of one tile often follow each other
             prc_load_tile<S, TILE>(s_tile, d.tile, org, contrib, nranks, span, slice, T);
@@ -672,7 +705,7 @@ pr_cold_accum_kernel(const prc_item2* __restrict__ items, int n_items, unsigned 
         for (int i = tid; i < LIMBS * BINROWS; i += PRC_THREADS) s_acc[i] = 0ull;
         __syncthreads();
         const int it = s_item;
-        if (it >= n_items) break;
+        if ((unsigned) it >= (unsigned) n_items) break;   // (unsigned: a counter that ran away from the host's copy ends the kernel)
         const prc_item2 d = items[it];
         const int npieces = (d.g1 - d.g0 + 7) >> 3;
         for (int base = 0; base < npieces; base += PRC_WAVES * PRC_UNROLL) {
@@ -1061,6 +1094,33 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
                        (const int32_t*) first.p, (const int32_t*) c1.p, (const uint32_t*) ckey.p, binbits,
                        (const uint8_t*) mode.p, Ec, nat.p);
     PRC_TRY(prc_exscan(nat.p, natpre.p, Ec + 1, tmp, s), "scan");   // natpre: pair ends before an edge
+    if (prc_env_int("GMX_PR_DEBUG", 0) >= 2) {
+        int32_t np = 0;
+        PRC_TRY(hipMemcpyAsync(&np, natpre.p + Ec, 4, hipMemcpyDeviceToHost, s), "copy");
+        PRC_TRY(hipStreamSynchronize(s), "sync");
+        dbuf<int32_t> len;
+        dbuf<unsigned long long> hist;
+        PRC_ALLOC(len, (size_t) np + 1);
+        PRC_ALLOC(hist, 32);
+        PRC_TRY(hipMemsetAsync(len.p, 0, sizeof(int32_t) * ((size_t) np + 1), s), "memset");
+        PRC_TRY(hipMemsetAsync(hist.p, 0, sizeof(unsigned long long) * 32, s), "memset");
+        hipLaunchKernelGGL(prc_dbg_pair_len_kernel, dim3(prc_grid_for(Ec)), dim3(256), 0, s, (const int32_t*) natpre.p, Ec, len.p);
+        hipLaunchKernelGGL(prc_dbg_len_hist_kernel, dim3(prc_grid_for(np)), dim3(256), 0, s, (const int32_t*) len.p, (int64_t) np, hist.p);
+        unsigned long long hh[32];
+        PRC_TRY(hipMemcpyAsync(hh, hist.p, sizeof(hh), hipMemcpyDeviceToHost, s), "copy");
+        PRC_TRY(hipStreamSynchronize(s), "sync");
+        fprintf(stderr, "gmx pr cold: pair lengths (all tiles, after the cuts): bucket <= 2^b : pairs / edges\n");
+        for (int b = 0; b < 16; b++)
+            if (hh[2 * b]) fprintf(stderr, "   <= %5d : %12llu / %12llu\n", 1 << b, hh[2 * b], hh[2 * b + 1]);
+        fprintf(stderr, "gmx pr cold: per tile (first 48, then every 64th): tile form groups pairs edges edges/pair\n");
+        for (int64_t t = 0; t < c->ntiles; t++) {
+            if (t >= 48 && t % 64) continue;
+            const int64_t g = (int64_t) ht[4 * (t + 1) + 1] - ht[4 * t + 1], npt = (int64_t) ht[4 * (t + 1) + 2] - ht[4 * t + 2],
+                          ne = (int64_t) ht[4 * (t + 1) + 3] - ht[4 * t + 3];
+            fprintf(stderr, "   %5lld %d %9lld %9lld %10lld %.2f\n", (long long) t, (int) hmode[t], (long long) g, (long long) npt, (long long) ne,
+                    npt ? (double) ne / (double) npt : 0.0);
+        }
+    }
     PRC_ALLOC(counts, nc + 1);
     PRC_ALLOC(key2, nc);
     PRC_ALLOC(key2s, nc);
@@ -1136,6 +1196,16 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
         }
         PRC_ALLOC(c->torg, horg.size());
         PRC_TRY(hipMemcpy(c->torg.p, horg.data(), sizeof(int32_t) * horg.size(), hipMemcpyHostToDevice), "copy");
+    }
+    if (prm.deg_by_id) {   // per tile: the largest out-degree of its sources
+        dbuf<int32_t> tmax;
+        PRC_ALLOC(tmax, c->ntiles);
+        PRC_TRY(hipMemsetAsync(tmax.p, 0, sizeof(int32_t) * (size_t) c->ntiles, s), "memset");
+        const int64_t nids = (int64_t) prm.nranks * prm.slice;
+        hipLaunchKernelGGL(prc_tile_maxdeg_kernel, dim3(prc_grid_for(nids)), dim3(256), 0, s, prm.deg_by_id, nids, prm.slice, prm.T, tile_src, tmax.p);
+        c->tile_maxdeg.assign((size_t) c->ntiles, 0);
+        PRC_TRY(hipMemcpyAsync(c->tile_maxdeg.data(), tmax.p, sizeof(int32_t) * (size_t) c->ntiles, hipMemcpyDeviceToHost, s), "copy");
+        PRC_TRY(hipStreamSynchronize(s), "sync");
     }
     // ---- work lists ----
     {
@@ -1295,6 +1365,23 @@ int pr_cold_launch(pr_cold* c, const void* contrib, const pr_cold_fuse* fuse, hi
 const double* pr_cold_diff_partials(const pr_cold* c, int64_t* n) {
     *n = c ? c->n2 + c->n3 * (c->binrows / 64) : 0;
     return c ? c->diffp.p : nullptr;
+}
+
+// The fp32 form adds the pair sums (fp32 values) into ONE limb of 2^-62: a value >= 2^-39 converts exactly, a smaller
+// one loses less than 2^-62.  A pair sum is at least the smallest contribution of its tile, and a contribution is at
+// least (1-d)/N / outdeg (every rank is >= the teleport term), so only tiles holding a source of out-degree
+// > (1-d)/N * 2^39 can produce inexact terms: R such tiles give a row at most R * (1 + TILE/512) truncated terms
+// (pairs are cut at the ends of 512-entry blocks), i.e. an absolute error below R * 64 * 2^-62 in its sum and
+// d * that in its rank, which is >= (1-d)/N.  The guard asks for a quarter of the 1e-6 bar (2^-22 relative).
+// False (d = 1 included: no teleport term, nothing bounds a rank from below) sends the caller to the fp64 plan.
+bool pr_cold_limb_guard(const pr_cold* c, double d, double N) {
+    if (!c || c->Ec == 0 || c->limbs > 1) return true;
+    if (!(d > 0.0 && d < 1.0)) return false;
+    if (c->tile_maxdeg.empty()) return false;
+    const double base = (1.0 - d) / N, dstar = base * 0x1p39;
+    int64_t risky = 0;
+    for (int32_t m : c->tile_maxdeg) risky += (double) m > dstar;
+    return (double) risky * 64.0 * 0x1p-62 * d <= 0x1p-22 * base;
 }
 
 // every active row lies in a bin that has at least one item: the fused finish then visits all of them

@@ -7,7 +7,7 @@
 //
 //   ranks      GMX_PR_RANKS (default: the devices in use); rank r lives on device r % devices, so several rank
 //              states can share a device (how the one-GPU test box exercises the orchestration)
-//   devices    GMX_DEVICES (default: all visible)
+//   devices    GMX_DEVICES=<n> | all (the path is opt-in: without GMX_DEVICES / GMX_PR_RANKS the entry stays on one device)
 //   graph      the CSR is copied once to every other device in use (replicated, as 8e prescribes) and cached
 //   step       every rank's sweep is enqueued on its own stream; behind it, on the same stream, the rank's new
 //              contributions go straight into every other rank's replica (hipMemcpyPeerAsync: the copy engines over
@@ -76,6 +76,7 @@ struct gmx_pr_multi {
     std::vector<hipEvent_t> landed;       // same index
     std::vector<hipEvent_t> computed;     // [r * 2 + c]
     int home = 0;                         // device the caller's graph lives on
+    bool verified = false;                // the first exchange has been checked against the owners' ranges (verify_replicas)
     ~gmx_pr_multi() {
         for (size_t r = 0; r < pr.size(); r++) {
             (void) hipSetDevice(dev[r]);
@@ -112,11 +113,17 @@ static int env_int(const char* name, int dflt) {
     return v && *v ? atoi(v) : dflt;
 }
 
-// ranks the whole-kernel entry would use for this graph (1: the single-GPU path)
+// ranks the whole-kernel entry would use for this graph (1: the single-GPU path).  Several GPUs are OPT-IN: an unchanged
+// caller on a shared multi-GPU node keeps to the device its graph lives on unless GMX_DEVICES (how many devices to use,
+// "all" = every visible one) or GMX_PR_RANKS (rank states; more than devices = several per device, the one-GPU test
+// form) is set.
 int gmx_pr_multi_ranks(const gmx_graph* g) {
+    const char* ed = getenv("GMX_DEVICES");
+    const char* er = getenv("GMX_PR_RANKS");
+    if (!(ed && *ed) && !(er && *er)) return 1;
     int ndev = 1;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) ndev = 1;
-    const int want_dev = env_int("GMX_DEVICES", ndev);
+    const int want_dev = (ed && !strcmp(ed, "all")) ? ndev : env_int("GMX_DEVICES", er && *er ? ndev : 1);
     if (want_dev >= 1 && want_dev < ndev) ndev = want_dev;
     int nranks = env_int("GMX_PR_RANKS", ndev);
     if (nranks < 1) nranks = 1;
@@ -155,7 +162,8 @@ int gmx_pr_multi_create(gmx_graph* g, int elem, int nranks, gmx_pr_multi** out) 
     do {
         int ndev = 1;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) ndev = 1;
-        const int want_dev = env_int("GMX_DEVICES", ndev);
+        const char* ed = getenv("GMX_DEVICES");
+        const int want_dev = (ed && !strcmp(ed, "all")) ? ndev : env_int("GMX_DEVICES", ndev);
         if (want_dev >= 1 && want_dev < ndev) ndev = want_dev;
         if (ndev > nranks) ndev = nranks;
         m->nranks = nranks;
@@ -309,6 +317,61 @@ static int exchange(gmx_pr_multi* m) {
     return GMX_OK;
 }
 
+// First contact.  The peer copies (or RCCL calls) of this path cannot be exercised on the one-GPU development boxes,
+// so the first exchange of a gmx_pr_multi is checked before anything is computed from it: every rank's replica must
+// hold, in every other rank's range, exactly the words the owner holds there.  Word compare on the receiving device
+// (the owner's range is fetched with one more peer copy into scratch).  A mismatch makes gmx_pr_multi_run return
+// GMX_ERR_STATE with `verified` still false; the entry then notes it on stderr and runs the single-GPU path.
+__global__ void prm_compare_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, int64_t n, unsigned long long* __restrict__ bad) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    unsigned long long c = 0;
+    for (; i < n; i += stride) c += a[i] != b[i];
+    if (c) atomicAdd(bad, c);
+}
+
+struct prm_event {   // released on every return path
+    hipEvent_t e = nullptr;
+    ~prm_event() { if (e) (void) hipEventDestroy(e); }
+};
+
+static int verify_replicas(gmx_pr_multi* m) {
+    void* sp = nullptr;
+    int64_t slice = 0, need = 0;
+    GMX_CHECK(gmx_pr_contrib_slice(m->pr[0], &sp, &slice));
+    GMX_CHECK(gmx_pr_exchange_count(m->pr[0], &need));
+    for (int r = 0; r < m->nranks; r++) {
+        GMX_HIP(hipSetDevice(m->dev[r]));
+        GMX_HIP(hipStreamSynchronize(m->stream[r]));
+    }
+    const size_t es = (size_t) m->elem, words = (size_t) need * es / 4;
+    unsigned long long total_bad = 0;
+    for (int q = 0; q < m->nranks && words > 0; q++) {
+        GMX_HIP(hipSetDevice(m->dev[q]));
+        dbuf<uint32_t> tmp;
+        dbuf<unsigned long long> bad;
+        GMX_CHECK(tmp.alloc(words));
+        GMX_CHECK(bad.alloc(1));
+        GMX_HIP(hipMemset(bad.p, 0, sizeof(unsigned long long)));
+        for (int r = 0; r < m->nranks; r++) {
+            if (r == q) continue;
+            const size_t at = (size_t) r * (size_t) slice * es;
+            GMX_HIP(hipMemcpyPeer(tmp.p, m->dev[q], replica(m, r) + at, m->dev[r], words * 4));
+            hipLaunchKernelGGL(prm_compare_kernel, dim3(1024), dim3(256), 0, 0, (const uint32_t*) tmp.p, (const uint32_t*) (replica(m, q) + at), (int64_t) words, bad.p);
+            GMX_HIP(hipDeviceSynchronize());
+        }
+        unsigned long long hb = 0;
+        GMX_HIP(hipMemcpy(&hb, bad.p, sizeof(hb), hipMemcpyDeviceToHost));
+        total_bad += hb;
+    }
+    if (total_bad) {
+        gmx_set_error("multi-GPU pagerank: first exchange failed its check (%llu words differ between a replica and the owner's range)", total_bad);
+        return GMX_ERR_STATE;
+    }
+    m->verified = true;
+    return GMX_OK;
+}
+
 // do { sweep; exchange; diff } while (diff > e && cnt < max)   (pagerank.gm:9-19), then the ranks of every rank's rows
 // One pipelined iteration of all ranks (peer copies, two row chunks; the order of DistPageRank._step_pipelined with
 // events in place of barriers -- one host thread sees every stream):
@@ -372,13 +435,15 @@ int gmx_pr_multi_run(gmx_pr_multi* m, double e, double d, int32_t max_iter, void
         GMX_HIP(hipSetDevice(m->dev[r]));
         GMX_CHECK(gmx_pr_reset(m->pr[r], d));
     }
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    prm_event g0, g1;
     GMX_HIP(hipSetDevice(m->dev[0]));
-    GMX_HIP(hipEventCreate(&ev0));
-    GMX_HIP(hipEventCreate(&ev1));
+    GMX_HIP(hipEventCreate(&g0.e));
+    GMX_HIP(hipEventCreate(&g1.e));
+    hipEvent_t ev0 = g0.e, ev1 = g1.e;
     int st = GMX_OK;
     do {
         if ((st = exchange(m))) break;   // the reset filled every rank's own range of the current replica only
+        if (!m->verified && m->nranks > 1 && (st = verify_replicas(m))) break;
         GMX_HIP(hipSetDevice(m->dev[0]));
         (void) hipEventRecord(ev0, m->stream[0]);
         do {
@@ -437,8 +502,8 @@ int gmx_pr_multi_run(gmx_pr_multi* m, double e, double d, int32_t max_iter, void
             stats->d2h_ms = t0;
         }
     } while (0);
-    (void) hipEventDestroy(ev0);
-    (void) hipEventDestroy(ev1);
     (void) hipSetDevice(m->home);
     return st;
 }
+
+bool gmx_pr_multi_verified(const gmx_pr_multi* m) { return m && m->verified; }

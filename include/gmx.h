@@ -125,8 +125,9 @@ typedef struct {
  * rank_host[V] is caller-owned (pagerank_main.cc:18-25) and written on return. */
 int gmx_pagerank_f64(gmx_graph_t* g, double e, double d, int32_t max_iter,
                      double* rank_host, gmx_stats_t* stats);
-/* Node_Prop<Float> variant (BASELINE config 2): fp32 STORAGE, row sums in fp64 / 64-bit fixed point, one rounding
- * per vertex.  Within 1e-6 relative of the fp64 result; not bit- or iteration-comparable with what gm_comp would emit
+/* Node_Prop<Float> variant (BASELINE config 2): fp32 STORAGE; partial row sums are formed in fp64, rounded to fp32 once
+ * per (source tile, row) pair, added exactly in 64-bit fixed point and rounded once more per vertex.  Within 1e-6
+ * relative of the fp64 result; not bit- or iteration-comparable with what gm_comp would emit
  * for a Float property (fp32 sums in thread order), whose iteration count near the threshold e may differ. */
 int gmx_pagerank_f32(gmx_graph_t* g, float e, float d, int32_t max_iter,
                      float* rank_host, gmx_stats_t* stats);
@@ -253,6 +254,9 @@ int gmx_pr_push_join(gmx_pr_t* p, void* stream);
  * and the caller may start class 0 of the next step as soon as every rank's LAST chunk has landed
  * (gmx_pr_push_join_chunk(p, chunks-1, s) + its barrier), while the earlier chunks are still travelling; class 1
  * waits for those.  Without the gather calls gmx_pr_step_chunk(p, 0, s) enqueues phase 1 itself. */
+/* All launches of one gmx_pr_t (gmx_pr_step, gmx_pr_step_gather, gmx_pr_step_chunk) must be enqueued in call order on
+ * ONE stream: the persistent kernels of the binned sweep draw their work from device counters that advance from
+ * launch to launch, and the host passes each launch the value it expects to find. */
 int gmx_pr_gather_classes(gmx_pr_t* p, int* classes);
 int gmx_pr_gather_items(gmx_pr_t* p, int tile_class, int64_t* items);   /* phase-1 work items of a class (set by gmx_pr_set_chunks) */
 int gmx_pr_step_gather(gmx_pr_t* p, int tile_class, void* stream);
