@@ -68,7 +68,45 @@ static constexpr int prc_tile_elems(int elem) { return (PRC_LDS_LIMIT - 16 * (PR
 #define PRC_CHECK(cond) do { } while (0)
 #endif
 
-struct prc_item1 { int32_t tile, g0, g1, form; };         // phase 1: groups [g0, g1) of the tile-major stream; form 1 = pair, 0 = edge
+// Length classes (round 3).  The generic pair form spends ~230 VALU instructions on every 512-entry block whatever the
+// block holds, and phase 1 was VALU-bound on it.  In the tiles that hold most of the edges the pairs
+// are therefore sorted, at plan time, into CLASSES with a regular shape, each class a stream of its own ("virtual
+// tile" = tile * 8 + class in the sort key), so that the kernel needs neither per-entry flags nor scans nor staging:
+//   E1 / E2 / E4 / E8   pairs of 1 / 2 / 3-4 / 5-8 edges, padded to 1 / 2 / 4 / 8 entries: a lane (8 entries, one
+//                       16-byte load) owns 8 / 4 / 2 / 1 whole pairs, sums them in fp64 in entry order and stores the
+//                       results as one vector into consecutive item slots -- no cross-lane step at all;
+//   H                   pairs of 9 or more edges, padded to whole lanes (multiples of 8 entries): every lane belongs to
+//                       ONE pair, the only flag is "this lane closes its pair" (on the lane's last entry, which may be
+//                       a padding entry), one segmented wave scan of the lane sums, at most 64 results per block,
+//                       staged and stored with ONE store instruction per block;
+//   class 0             the generic pair form / the edge form of round 2, kept for the tiles whose (tile, bin) cells are
+//                       too small to be cut five ways (every (class, bin) sub-cell is padded to a group of 32 entries).
+#define PRC_CLS_BITS 3
+enum { PRC_CL_GEN = 0, PRC_CL_E1 = 1, PRC_CL_E2 = 2, PRC_CL_E4 = 3, PRC_CL_E8 = 4, PRC_CL_H = 5 };
+enum { PRC_FORM_EDGE = 0, PRC_FORM_PAIR = 1, PRC_FORM_E1 = 2, PRC_FORM_E2 = 3, PRC_FORM_E4 = 4, PRC_FORM_E8 = 5, PRC_FORM_H = 6,
+       PRC_FORM_TILE = 7 };   // TILE: a run of groups of a classed tile; the class streams it crosses come from the stream table
+enum { PRC_TM_EDGE = 0, PRC_TM_PAIR = 1, PRC_TM_CLASSED = 2 };   // how a tile is stored
+__host__ __device__ static inline int prc_class_of_len(int len) { return len <= 1 ? PRC_CL_E1 : len == 2 ? PRC_CL_E2 : len <= 4 ? PRC_CL_E4 : len <= 8 ? PRC_CL_E8 : PRC_CL_H; }
+__host__ __device__ static inline int prc_padded_len(int cls, int len) {
+    return cls == PRC_CL_GEN ? len : cls == PRC_CL_H ? (len + 7) & ~7 : 1 << (cls - 1);
+}
+
+// How many 16-byte stores a lane of class E_L issues for element size `elem`, and the interleave that goes with it.
+// With ONE store per lane (fp32 E2 / E4 / E8, fp64 E4 / E8) consecutive lanes hold consecutive results and the store
+// instruction writes whole lines.  With K > 1 stores (fp32 E1, fp64 E1 / E2) that layout makes every instruction write a
+// 16-byte piece out of each lane's 32 or 64 bytes -- K partial writes per line, and the L2 takes a transaction for each
+// (measured: the fp64 class kernel ran at half the HBM rate).  Those classes are therefore laid out in OCTETS at plan
+// time (prc_interleaved_pos): 8 lanes own the results of two groups, and lane m's q-th store holds results
+// [R m, R m + R) of the q-th 128-byte chunk of those two groups' results -- every instruction writes whole lines.
+__host__ __device__ static inline int prc_e_stores(int L, int elem) { return ((8 / L) * elem + 15) / 16; }
+// position of entry j of result i (of 32 / L) of absolute group G in the stream, for an interleaved class
+__host__ __device__ static inline int64_t prc_interleaved_pos(int L, int elem, int64_t G, int i, int j) {
+    const int K = prc_e_stores(L, elem), R = 16 / elem, cpg = K / 2;   // chunks (8 R results) per group
+    const int ch = i / (8 * R), within = i % (8 * R), m = within / R, r = within % R, q = (int) (G & 1) * cpg + ch;
+    return (G & ~(int64_t) 1) * PRC_G + 8 * m + (q * R + r) * L + j;
+}
+
+struct prc_item1 { int32_t tile, g0, g1, form; };         // phase 1: groups [g0, g1) of the tile-major stream of a (physical) tile; form PRC_FORM_*
 struct prc_item2 { int32_t bin, g0, g1, slot; };          // phase 2: groups [g0, g1) of the bin-major stream; slot < 0: sole chunk
 struct prc_item3 { int32_t bin, slot0, nslots, pad; };    // phase 3: a split bin
 
@@ -88,18 +126,20 @@ struct pr_cold {
     dbuf<char> cold;         // [nactive] x elem
     dbuf<prc_item1> it1p;    // pair items, then edge items
     dbuf<int32_t> torg;      // [2 * ntiles] rank range and offset behind the hot/cold border where a tile starts
+    dbuf<int32_t> vstart;    // [8 * ntiles + 1] first group of every (tile, class) stream
     dbuf<prc_item2> it2;
     dbuf<prc_item3> it3;
     int64_t n1p = 0, n1e = 0, n2 = 0, n3 = 0, nslots = 0;
     // The step can be cut into parts (pr_cold_set_parts): phase 1 by tile CLASS (0: every live source of the tile lies
     // in the hub piece of its rank range, 1: the rest), phases 2-3 by row part (bins), in processing order.
-    std::vector<prc_item1> h1p, h1e;    // host copies of the work lists, in the order they were made
+    std::vector<prc_item1> h1p, h1e;    // host copies of the work lists, in the order they were made (h1e: edge-form items)
     std::vector<prc_item2> h2;
     std::vector<prc_item3> h3;
     int nparts = 1;
-    int64_t o1[3] = {0, 0, 0};          // it1p: items [o1[k], o1[k + 1]) belong to tile class k
+    int64_t o1[3] = {0, 0, 0};          // it1p: items [o1[k], o1[k + 1]) belong to tile class k ...
+    int64_t o1g[2] = {0, 0};            // ... the class-form items first, the generic pair / edge items from o1g[k]
     std::vector<int64_t> o2, o3, o3few; // it2 / it3: items [o[c], o[c + 1]) belong to part c; the first o3few[c] of a part's it3 items have few slots
-    uint32_t q1 = 0, q2 = 0;            // what the work counters of phase 1 / 2 hold before the next launch
+    uint32_t q1 = 0, q1c = 0, q2 = 0;   // what the work counters of phase 1 (generic, class forms) / 2 hold before the next launch
     dbuf<unsigned long long> scratch;   // [nslots][limbs][binrows]
     dbuf<unsigned int> queue;           // [3 * 64]
     dbuf<double> diffp;                 // fused finish: [n2] partials of phase 2, then [n3 * binrows / 64] of phase 3
@@ -116,8 +156,8 @@ static int prc_grid_for(int64_t n, int block = 256) {
 }
 
 // ------------------------------------------------------------------ plan kernels
-// key' = tile | bin | bin-local row | tile-local source   (a tile holds tile_src = TILE - 1 sources: the last LDS
-// slot stays zero and is what padding entries point at)
+// key' = tile | class | bin | bin-local row | tile-local source   (a tile holds tile_src = TILE - 1 sources: the last LDS
+// slot stays zero and is what padding entries point at).  The class field is 0 until prc_class_kernel fills it.
 __global__ void prc_keys_kernel(const uint64_t* __restrict__ keys, int64_t n, pr_cold_params prm, int tile_src, int binrows,
                                 int binbits, uint64_t* __restrict__ out) {
     int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,34 +171,95 @@ __global__ void prc_keys_kernel(const uint64_t* __restrict__ keys, int64_t n, pr
         const int64_t cp = (src / prm.slice) * span + (src % prm.slice - prm.T);
         const uint64_t t = (uint64_t) (cp / tile_src), sl = (uint64_t) (cp % tile_src);
         const uint64_t b = (uint64_t) (a / binrows), rl = (uint64_t) (a % binrows);
-        out[i] = (t << (32 + binbits)) | (b << 32) | (rl << 16) | sl;
+        out[i] = (t << (32 + binbits + PRC_CLS_BITS)) | (b << 32) | (rl << 16) | sl;
     }
 }
 
-// cflag: first edge of a cell.  nat: last edge of a (tile, row) pair.  Both arrays have n + 1 entries (last = 0).
-__global__ void prc_flag_kernel(const uint64_t* __restrict__ k, int64_t n, int32_t* __restrict__ cflag, int32_t* __restrict__ nat) {
+// cflag: first edge of a cell (same virtual tile and bin).  ps: first edge of a (virtual tile, row) pair.  n entries each.
+__global__ void prc_runs_kernel(const uint64_t* __restrict__ k, int64_t n, int32_t* __restrict__ cflag, int32_t* __restrict__ ps) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        cflag[i] = (i == 0 || (k[i] >> 32) != (k[i - 1] >> 32)) ? 1 : 0;
+        ps[i] = (i == 0 || (k[i] >> 16) != (k[i - 1] >> 16)) ? 1 : 0;
+    }
+}
+
+// pstart[p] = first edge of pair p; pstart[np] = n
+__global__ void prc_pair_start_kernel(const int32_t* __restrict__ ps, const int32_t* __restrict__ pincl, int64_t n, int64_t np,
+                                      int32_t* __restrict__ pstart) {
     int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
     for (; i <= n; i += stride) {
-        if (i == n) { cflag[i] = 0; nat[i] = 0; continue; }
-        cflag[i] = (i == 0 || (k[i] >> 32) != (k[i - 1] >> 32)) ? 1 : 0;
-        nat[i] = (i == n - 1 || (k[i] >> 16) != (k[i + 1] >> 16)) ? 1 : 0;
+        if (i == n) { pstart[np] = (int32_t) n; continue; }
+        if (ps[i]) pstart[pincl[i] - 1] = (int32_t) i;
+    }
+}
+
+// per tile t (0..ntiles): its first edge, and the pairs / cells before it (keys sorted, class field still 0)
+__global__ void prc_tile_stats_kernel(const uint64_t* __restrict__ k, int64_t n, int shift, int64_t ntiles, const int32_t* __restrict__ pincl,
+                                      const int32_t* __restrict__ cincl, int64_t np, int64_t nc, int32_t* __restrict__ out) {
+    int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; t <= ntiles; t += stride) {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t) (k[mid] >> shift) < t) lo = mid + 1; else hi = mid;
+        }
+        out[3 * t + 0] = (int32_t) lo;
+        out[3 * t + 1] = lo < n ? pincl[lo] - 1 : (int32_t) np;
+        out[3 * t + 2] = lo < n ? cincl[lo] - 1 : (int32_t) nc;
+    }
+}
+
+// writes the class of every edge's pair into its key (tiles stored in classes only)
+__global__ void prc_class_kernel(uint64_t* __restrict__ k, int64_t n, const int32_t* __restrict__ pincl, const int32_t* __restrict__ pstart,
+                                 const uint8_t* __restrict__ mode, int binbits) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint64_t key = k[i];
+        if (mode[key >> (32 + binbits + PRC_CLS_BITS)] != PRC_TM_CLASSED) continue;
+        const int32_t p = pincl[i] - 1;
+        k[i] = key | ((uint64_t) prc_class_of_len(pstart[p + 1] - pstart[p]) << (32 + binbits));
+    }
+}
+
+// plen[p] = entries pair p occupies in the tile-major stream (plen[np] = 0)
+__global__ void prc_pair_len_kernel(const uint64_t* __restrict__ k, const int32_t* __restrict__ pstart, int64_t np, int binbits,
+                                    int32_t* __restrict__ plen) {
+    int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; p <= np; p += stride) {
+        if (p == np) { plen[p] = 0; continue; }
+        const int cls = (int) ((k[pstart[p]] >> (32 + binbits)) & ((1u << PRC_CLS_BITS) - 1));
+        plen[p] = prc_padded_len(cls, pstart[p + 1] - pstart[p]);
     }
 }
 
 // first[c] = position of the first edge of cell c (first[ncells] = n); ckey[c] = tile | bin
 __global__ void prc_cell_first_kernel(const uint64_t* __restrict__ k, const int32_t* __restrict__ cflag,
-                                      const int32_t* __restrict__ incl, int64_t n, int64_t ncells, int32_t* __restrict__ first,
-                                      uint32_t* __restrict__ ckey) {
+                                      const int32_t* __restrict__ incl, const int32_t* __restrict__ pincl, int64_t n, int64_t ncells, int64_t np,
+                                      int32_t* __restrict__ first, int32_t* __restrict__ pfirst, uint32_t* __restrict__ ckey) {
     int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
     for (; i <= n; i += stride) {
-        if (i == n) { first[ncells] = (int32_t) n; continue; }
+        if (i == n) { first[ncells] = (int32_t) n; pfirst[ncells] = (int32_t) np; continue; }
         if (cflag[i]) {
             first[incl[i] - 1] = (int32_t) i;
+            pfirst[incl[i] - 1] = pincl[i] - 1;     // a cell starts with a pair
             ckey[incl[i] - 1] = (uint32_t) (k[i] >> 32);
         }
     }
+}
+
+// tile-major groups of a cell: its pairs' padded lengths, rounded up to whole groups (groups[ncells] = 0)
+__global__ void prc_cell_entry_groups_kernel(const int32_t* __restrict__ pfirst, const int32_t* __restrict__ ppos, int64_t ncells,
+                                             int32_t* __restrict__ groups) {
+    int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; c <= ncells; c += stride) groups[c] = c < ncells ? (ppos[pfirst[c + 1]] - ppos[pfirst[c]] + PRC_G - 1) / PRC_G : 0;
 }
 
 // groups[c] = ceil(count / G) where count = pre[first[c + 1]] - pre[first[c]] (pre == NULL: the edges themselves);
@@ -175,22 +276,19 @@ __global__ void prc_cell_groups_kernel(const int32_t* __restrict__ first, const 
     }
 }
 
-// per tile t (0..ntiles): index of its first cell, and the raw group / natural pair / edge prefix there
-__global__ void prc_tile_table_kernel(const uint32_t* __restrict__ ckey, int64_t ncells, int binbits, int64_t ntiles,
-                                      const int32_t* __restrict__ c1raw, const int32_t* __restrict__ natpre,
-                                      const int32_t* __restrict__ first, int32_t* __restrict__ out) {
+// per virtual tile v (0..nvt): index of its first cell and the raw group prefix there
+__global__ void prc_vt_table_kernel(const uint32_t* __restrict__ ckey, int64_t ncells, int binbits, int64_t nvt,
+                                    const int32_t* __restrict__ c1raw, int32_t* __restrict__ out) {
     int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
-    for (; t <= ntiles; t += stride) {
+    for (; t <= nvt; t += stride) {
         int64_t lo = 0, hi = ncells;
         while (lo < hi) {
             const int64_t mid = (lo + hi) >> 1;
             if ((int64_t) (ckey[mid] >> binbits) < t) lo = mid + 1; else hi = mid;
         }
-        out[4 * t + 0] = (int32_t) lo;
-        out[4 * t + 1] = c1raw[lo];            // arrays have ncells + 1 entries
-        out[4 * t + 2] = natpre[first[lo]];
-        out[4 * t + 3] = first[lo];
+        out[2 * t + 0] = (int32_t) lo;
+        out[2 * t + 1] = c1raw[lo];            // arrays have ncells + 1 entries
     }
 }
 
@@ -202,18 +300,33 @@ __global__ void prc_cell_start_kernel(const int32_t* __restrict__ c1raw, const u
     for (; c < ncells; c += stride) c1[c] = c1raw[c] + delta[ckey[c] >> binbits];
 }
 
-// final end flags (in place over nat): pair tiles cut their pairs at the ends of the 512-entry blocks of the padded
-// stream; edge tiles make every edge an item
-__global__ void prc_final_flag_kernel(const int32_t* __restrict__ incl, const int32_t* __restrict__ first,
-                                      const int32_t* __restrict__ c1, const uint32_t* __restrict__ ckey, int binbits,
-                                      const uint8_t* __restrict__ pair_mode, int64_t n, int32_t* __restrict__ nat) {
+// Position of every edge in the padded tile-major stream, and whether it closes an ITEM: edge tiles make every edge an
+// item; the generic form and class H cut their pairs at the ends of the 512-entry blocks of the stream (a block then
+// needs nothing from its neighbours); the E classes have one item per pair.
+__global__ void prc_pos_end_kernel(const uint64_t* __restrict__ k, const int32_t* __restrict__ cincl, const int32_t* __restrict__ pincl,
+                                   const int32_t* __restrict__ pstart, const int32_t* __restrict__ ppos, const int32_t* __restrict__ pfirst,
+                                   const int32_t* __restrict__ c1, const uint8_t* __restrict__ mode, int binbits, int elem, int64_t n,
+                                   int32_t* __restrict__ pos, int32_t* __restrict__ endf) {
     int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        const int32_t c = incl[i] - 1;
-        const int64_t pos = (int64_t) c1[c] * PRC_G + (i - first[c]);
-        if (!pair_mode[ckey[c] >> binbits]) nat[i] = 1;
-        else if ((pos & (PRC_BLK_GROUPS * PRC_G - 1)) == PRC_BLK_GROUPS * PRC_G - 1) nat[i] = 1;
+    for (; i <= n; i += stride) {
+        if (i == n) { endf[i] = 0; continue; }
+        const int32_t c = cincl[i] - 1, p = pincl[i] - 1;
+        const uint32_t vt = (uint32_t) (k[i] >> (32 + binbits));
+        const int cls = (int) (vt & ((1u << PRC_CLS_BITS) - 1));
+        int64_t at = (int64_t) c1[c] * PRC_G + (ppos[p] - ppos[pfirst[c]]) + (i - pstart[p]);
+        if (cls >= PRC_CL_E1 && cls <= PRC_CL_E8 && prc_e_stores(1 << (cls - 1), elem) > 1) {   // octet layout (see prc_interleaved_pos)
+            const int L = 1 << (cls - 1), rel = (int) (at & (PRC_G - 1));
+            at = prc_interleaved_pos(L, elem, at / PRC_G, rel / L, rel % L);
+        }
+        pos[i] = (int32_t) at;
+        const bool last = i + 1 == pstart[p + 1];
+        const bool cut = (at & (PRC_BLK_GROUPS * PRC_G - 1)) == PRC_BLK_GROUPS * PRC_G - 1;
+        int e;
+        if (mode[vt >> PRC_CLS_BITS] == PRC_TM_EDGE) e = 1;
+        else if (cls == PRC_CL_GEN || cls == PRC_CL_H) e = last || cut;
+        else e = last;
+        endf[i] = e;
     }
 }
 
@@ -245,27 +358,40 @@ __global__ void prc_fill_u16_kernel(uint16_t* __restrict__ p, int64_t n, uint16_
     for (; i < n; i += stride) p[i] = v;
 }
 
-// edge i of cell c: entry srcl[c1[c] * G + o]; if it ends a pair, item rowl[c2[c] * G + (ends before it in the cell)]
-__global__ void prc_fill_items_kernel(const uint64_t* __restrict__ k, const int32_t* __restrict__ incl,
-                                      const int32_t* __restrict__ first, const int32_t* __restrict__ c1,
+// edge i -> its entry in the tile-major stream; if it closes an item, the item's row number in the bin-major stream.
+// Class H keeps its only flag on the LAST entry of a lane: when the item does not end there, the flag goes onto the
+// padding entry that does (padding entries point at the tile's zero slot).
+__global__ void prc_fill_items_kernel(const uint64_t* __restrict__ k, const int32_t* __restrict__ cincl,
+                                      const int32_t* __restrict__ first, const int32_t* __restrict__ pos,
                                       const int32_t* __restrict__ c2, const int32_t* __restrict__ endf,
-                                      const int32_t* __restrict__ endpre, int64_t n, uint16_t* __restrict__ srcl,
-                                      uint16_t* __restrict__ rowl) {
+                                      const int32_t* __restrict__ endpre, int binbits, uint16_t zero_slot, int64_t n,
+                                      uint16_t* __restrict__ srcl, uint16_t* __restrict__ rowl) {
     int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
-        const int32_t c = incl[i] - 1;
-        const int64_t o = i - first[c];
+        const int32_t c = cincl[i] - 1;
         const uint32_t lo = (uint32_t) k[i];
-        srcl[(int64_t) c1[c] * PRC_G + o] = (uint16_t) ((lo & 0x7fffu) | (endf[i] ? PRC_END : 0u));
-        if (endf[i]) rowl[(int64_t) c2[c] * PRC_G + (endpre[i] - endpre[first[c]])] = (uint16_t) (lo >> 16);
+        const int cls = (int) ((k[i] >> (32 + binbits)) & ((1u << PRC_CLS_BITS) - 1));
+        const int64_t at = pos[i];
+        const bool e = endf[i] != 0;
+        if (cls == PRC_CL_H) {
+            if (e && (at & 7) != 7) {
+                srcl[at] = (uint16_t) (lo & 0x7fffu);
+                srcl[at | 7] = (uint16_t) (zero_slot | PRC_END);
+            } else srcl[at] = (uint16_t) ((lo & 0x7fffu) | (e ? PRC_END : 0u));
+        } else srcl[at] = (uint16_t) ((lo & 0x7fffu) | (e ? PRC_END : 0u));
+        if (e) rowl[(int64_t) c2[c] * PRC_G + (endpre[i] - endpre[first[c]])] = (uint16_t) (lo >> 16);
     }
 }
 
-// tile-major group g -> item slot of the first pair that ends in it (groups in the padding between tiles: 0, unused)
-__global__ void prc_fill_ob_kernel(const int32_t* __restrict__ c1, const int32_t* __restrict__ c2,
-                                   const int32_t* __restrict__ first, const int32_t* __restrict__ endpre, int64_t ncells,
-                                   int64_t ngroups, int32_t* __restrict__ ob) {
+// tile-major group g -> item slot its first item goes to.  Generic / edge form: the first pair that ends in the group.
+// E classes: the group's first pair (a group holds 32 / L whole pairs).  Class H: the first piece that ends at or
+// behind the group's start.  Groups of a class stream that lie in the padding behind a cell or a stream get `pad_slot`
+// (the E forms store every lane's results: padding must land outside the items); elsewhere 0, unused.
+__global__ void prc_fill_ob_kernel(const int32_t* __restrict__ c1, const int32_t* __restrict__ c2, const int32_t* __restrict__ first,
+                                   const int32_t* __restrict__ pfirst, const int32_t* __restrict__ pstart, const int32_t* __restrict__ ppos,
+                                   const int32_t* __restrict__ endpre, const uint32_t* __restrict__ ckey, int binbits, int64_t ncells,
+                                   int64_t ngroups, int32_t pad_slot, int32_t* __restrict__ ob) {
     int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
     for (; g < ngroups; g += stride) {
@@ -277,8 +403,23 @@ __global__ void prc_fill_ob_kernel(const int32_t* __restrict__ c1, const int32_t
         const int64_t c = lo - 1;
         int32_t v = 0;
         if (c >= 0) {
-            const int64_t e0 = (int64_t) first[c] + (g - c1[c]) * PRC_G;
-            if (e0 < first[c + 1]) v = c2[c] * PRC_G + (endpre[e0] - endpre[first[c]]);
+            const int cls = (int) ((ckey[c] >> binbits) & ((1u << PRC_CLS_BITS) - 1));
+            const int32_t p0 = pfirst[c];
+            const int64_t x = (g - c1[c]) * PRC_G, entries = ppos[pfirst[c + 1]] - ppos[p0];
+            const int32_t slot0 = c2[c] * PRC_G;
+            if (x >= entries) v = cls != PRC_CL_GEN ? pad_slot : 0;
+            else if (cls == PRC_CL_GEN) v = slot0 + (endpre[first[c] + x] - endpre[first[c]]);   // no padding inside the cell: entry offset = edge offset
+            else if (cls != PRC_CL_H) v = slot0 + (int32_t) ((g - c1[c]) * (PRC_G >> (cls - 1)));
+            else {
+                int64_t a = p0, b = pfirst[c + 1];   // the pair whose (padded) entries hold offset x: last one starting at or before x
+                while (b - a > 1) {
+                    const int64_t mid = (a + b) >> 1;
+                    if ((int64_t) ppos[mid] - ppos[p0] <= x) a = mid; else b = mid;
+                }
+                const int64_t abs_pair = (int64_t) c1[c] * PRC_G + (ppos[a] - ppos[p0]), abs_g = (int64_t) c1[c] * PRC_G + x;
+                const int64_t cuts = abs_g / (PRC_BLK_GROUPS * PRC_G) - abs_pair / (PRC_BLK_GROUPS * PRC_G);   // block ends inside the pair before the group
+                v = slot0 + (endpre[pstart[a]] - endpre[first[c]]) + (int32_t) cuts;
+            }
         }
         ob[g] = v;
     }
@@ -296,24 +437,6 @@ __global__ void prc_bin_table_kernel(const uint32_t* __restrict__ key2s, const i
             if ((int64_t) (key2s[mid] >> tilebits) < t) lo = mid + 1; else hi = mid;
         }
         table[t] = lo < ncells ? c2s[lo] : (int32_t) ngroups;
-    }
-}
-
-// GMX_PR_DEBUG=2: how long the (tile, row) pairs are.  len[p] += 1 per edge of pair p, then log2 buckets weighted by edges.
-__global__ void prc_dbg_pair_len_kernel(const int32_t* __restrict__ pairidx, int64_t n, int32_t* __restrict__ len) {
-    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
-    for (; i < n; i += stride) atomicAdd(&len[pairidx[i]], 1);
-}
-__global__ void prc_dbg_len_hist_kernel(const int32_t* __restrict__ len, int64_t np, unsigned long long* __restrict__ hist) {
-    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
-    for (; i < np; i += stride) {
-        const int l = len[i];
-        if (l <= 0) continue;
-        const int b = 32 - __clz(l - 1 > 0 ? l - 1 : 0);   // 1 -> 0, 2 -> 1, 3-4 -> 2, 5-8 -> 3, ...
-        atomicAdd(&hist[2 * (b < 15 ? b : 15)], 1ull);
-        atomicAdd(&hist[2 * (b < 15 ? b : 15) + 1], (unsigned long long) l);
     }
 }
 
@@ -587,6 +710,214 @@ __device__ __forceinline__ void prc_pair_item(const prc_item1 d, const S* __rest
 #undef PRC_PROCESS
 }
 
+// ---- the class forms (see the top of the file) ----
+typedef float prc_f32x2 __attribute__((ext_vector_type(2)));
+typedef double prc_f64x2 __attribute__((ext_vector_type(2)));
+
+// store instructions one block of a form issues (exactly: the prefetch waits count them)
+template <typename S, int FORM> struct prc_form_stores {
+    static constexpr int NP = FORM == PRC_FORM_H ? 1 : 8 >> (FORM - PRC_FORM_E1);     // results per lane
+    static constexpr int value = (NP * (int) sizeof(S) + 15) / 16;
+};
+
+// NP consecutive results of a lane -> val[slot ..], in 16-byte pieces (slot is a multiple of NP by construction)
+template <typename S, int NP> __device__ __forceinline__ void prc_store_results(S* __restrict__ dst, const S (&out)[NP]);
+template <> __device__ __forceinline__ void prc_store_results<float, 1>(float* __restrict__ dst, const float (&out)[1]) { __builtin_nontemporal_store(out[0], dst); }
+template <> __device__ __forceinline__ void prc_store_results<float, 2>(float* __restrict__ dst, const float (&out)[2]) {
+    prc_f32x2 v; v.x = out[0]; v.y = out[1];
+    __builtin_nontemporal_store(v, (prc_f32x2*) dst);
+}
+template <> __device__ __forceinline__ void prc_store_results<float, 4>(float* __restrict__ dst, const float (&out)[4]) {
+    prc_f32x4 v; v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
+    __builtin_nontemporal_store(v, (prc_f32x4*) dst);
+}
+template <> __device__ __forceinline__ void prc_store_results<float, 8>(float* __restrict__ dst, const float (&out)[8]) {
+    prc_f32x4 a, b; a.x = out[0]; a.y = out[1]; a.z = out[2]; a.w = out[3]; b.x = out[4]; b.y = out[5]; b.z = out[6]; b.w = out[7];
+    __builtin_nontemporal_store(a, (prc_f32x4*) dst);
+    __builtin_nontemporal_store(b, (prc_f32x4*) dst + 1);
+}
+template <> __device__ __forceinline__ void prc_store_results<double, 1>(double* __restrict__ dst, const double (&out)[1]) { __builtin_nontemporal_store(out[0], dst); }
+template <> __device__ __forceinline__ void prc_store_results<double, 2>(double* __restrict__ dst, const double (&out)[2]) {
+    prc_f64x2 v; v.x = out[0]; v.y = out[1];
+    __builtin_nontemporal_store(v, (prc_f64x2*) dst);
+}
+template <> __device__ __forceinline__ void prc_store_results<double, 4>(double* __restrict__ dst, const double (&out)[4]) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) { prc_f64x2 v; v.x = out[2 * q]; v.y = out[2 * q + 1]; __builtin_nontemporal_store(v, (prc_f64x2*) dst + q); }
+}
+template <> __device__ __forceinline__ void prc_store_results<double, 8>(double* __restrict__ dst, const double (&out)[8]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) { prc_f64x2 v; v.x = out[2 * q]; v.y = out[2 * q + 1]; __builtin_nontemporal_store(v, (prc_f64x2*) dst + q); }
+}
+
+// One block of an E class: the lane's 8 entries are 8 / L whole pairs of L entries (padding entries read the tile's zero
+// slot); `o` = item slot of the first pair of the lane's group.  fp64 sums in entry order, one rounding to S per pair.
+template <typename S, int L>
+__device__ __forceinline__ void prc_block_E(const S* __restrict__ s_tile, const prc_u32x4 cur, const int32_t o, S* __restrict__ val, const int lane) {
+    constexpr int NP = 8 / L;
+    constexpr int K = (NP * (int) sizeof(S) + 15) / 16;
+    const unsigned w[4] = {cur.x, cur.y, cur.z, cur.w};
+    S fv[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) fv[u] = s_tile[__builtin_amdgcn_ubfe(w[u >> 1], 16 * (u & 1), 15)];
+    S out[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        if (L == 1) out[q] = fv[q];
+        else {
+            double acc = (double) fv[q * L];
+#pragma unroll
+            for (int j = 1; j < L; j++) acc += (double) fv[q * L + j];
+            out[q] = (S) acc;
+        }
+    }
+    if constexpr (K == 1) {
+        PRC_CHECK(o >= 0 && (o & (NP - 1)) == 0);
+        prc_store_results<S, NP>(val + (o + (lane & 3) * NP), out);
+    } else {
+        // octet layout: stores 0 .. K/2-1 go to the even group of the lane's octet, the others to the odd one
+        constexpr int R = 16 / (int) sizeof(S), CPG = K / 2;
+        const int o_lo = __builtin_amdgcn_update_dpp(0, o, 0x114, 0xf, 0xf, true);    // row_shr:4  (from lane - 4)
+        const int o_hi = __builtin_amdgcn_update_dpp(0, o, 0x104, 0xf, 0xf, true);    // row_shl:4  (from lane + 4)
+        const bool upper = (lane & 4) != 0;
+        const int o_even = upper ? o_lo : o, o_odd = upper ? o : o_hi;
+        const int m = lane & 7;
+#pragma unroll
+        for (int q = 0; q < K; q++) {
+            S piece[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) piece[r] = out[q * R + r];
+            const int at = (q / CPG ? o_odd : o_even) + (q % CPG) * 8 * R + R * m;
+            PRC_CHECK(at >= 0 && (at & (R - 1)) == 0);
+            prc_store_results<S, R>(val + at, piece);
+        }
+    }
+}
+
+// One block of class H: every lane belongs to one pair; bit 15 of the lane's LAST entry = "the pair (or its piece in
+// this block) ends with this lane".  Lane sums in fp64, segmented inclusive scan over the lanes (a lane behind a
+// closing lane starts a new segment), the closing lanes stage their result at the ordinal of their piece, one store.
+template <typename S>
+__device__ __forceinline__ void prc_block_H(const S* __restrict__ s_tile, S* __restrict__ stage, const prc_u32x4 cur, const int32_t o,
+                                            S* __restrict__ val, const unsigned sink, const int lane) {
+    const unsigned w[4] = {cur.x, cur.y, cur.z, cur.w};
+    S fv[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) fv[u] = s_tile[__builtin_amdgcn_ubfe(w[u >> 1], 16 * (u & 1), 15)];
+    double v = (double) fv[0];
+#pragma unroll
+    for (int u = 1; u < 8; u++) v += (double) fv[u];
+    const int endm = __builtin_amdgcn_sbfe((int) w[3], 31, 1);                 // -1: closes its piece
+    int f = prc_dpp_i<PRC_DPP_WAVE_SHR1, 0xf>(endm) & 1;                        // the lane before closed one: a segment starts here
+    prc_seg_step<PRC_DPP_ROW_SHR(1), 0xf>(v, f);
+    prc_seg_step<PRC_DPP_ROW_SHR(2), 0xf>(v, f);
+    prc_seg_step<PRC_DPP_ROW_SHR(4), 0xf>(v, f);
+    prc_seg_step<PRC_DPP_ROW_SHR(8), 0xf>(v, f);
+    prc_seg_step<PRC_DPP_BCAST15, 0xa>(v, f);
+    prc_seg_step<PRC_DPP_BCAST31, 0xc>(v, f);
+    const unsigned long long ends = __ballot(endm != 0);
+    const int total = __builtin_popcountll(ends);
+    const int ord = (int) __builtin_amdgcn_mbcnt_hi((unsigned) (ends >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) ends, 0u));   // pieces closed by earlier lanes
+    // slot = ordinal + shift with one shift per group: o is the slot of the first piece that closes in the lane's group
+    const unsigned g4 = (unsigned) (ends >> (lane & ~3)) & 0xfu;                // the group's closing lanes
+    const int gbase = ord - __builtin_popcount(g4 & ((1u << (lane & 3)) - 1u));
+    const int shift = o - gbase;
+    const unsigned long long live = __ballot(g4 != 0u);
+    const int shift0 = __builtin_amdgcn_readlane(shift, live ? __builtin_ctzll(live) : 0);
+    const bool one_run = __ballot(g4 != 0u && shift != shift0) == 0ull;
+    const S x = (S) v;
+    unsigned at;
+    S y;
+    if (one_run) {
+        if (endm) stage[ord] = x;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+        y = stage[lane];
+        at = lane < total ? (unsigned) (shift0 + lane) : sink;
+        __builtin_amdgcn_wave_barrier();
+    } else {   // the block spans cells that are not adjacent in the bin-major order: every closing lane stores its own
+        y = x;
+        at = endm ? (unsigned) (shift + ord) : sink;
+    }
+    PRC_CHECK(at <= sink);
+    val[at] = y;   // exactly one store instruction per block on either path
+}
+
+template <typename S, int FORM>
+__device__ __forceinline__ void prc_class_block(const S* __restrict__ s_tile, S* __restrict__ stage, const prc_u32x4 cur, const int32_t o,
+                                                S* __restrict__ val, const unsigned sink, const int lane) {
+    if constexpr (FORM == PRC_FORM_H) prc_block_H<S>(s_tile, stage, cur, o, val, sink, lane);
+    else prc_block_E<S, 1 << (FORM - PRC_FORM_E1)>(s_tile, cur, o, val, lane);
+}
+
+#define PRC_SET_WAIT_N(t, N)                                                                                        \
+    asm volatile("s_waitcnt vmcnt(%8)"                                                                              \
+                 : "+v"((t).e0), "+v"((t).e1), "+v"((t).e2), "+v"((t).e3), "+v"((t).o0), "+v"((t).o1), "+v"((t).o2), "+v"((t).o3) \
+                 : "n"(N) : "memory")
+
+// One work item of a class form: blocks [0, nblocks) of 16 groups.  Whole super-steps (64 blocks: 4 per wave) run through
+// the same two-set prefetch as the generic form, with a block's exact store count in the waits; the blocks left over
+// (fewer than 64, the end of a class stream) are loaded plainly.
+template <typename S, int FORM>
+__device__ __forceinline__ void prc_class_item(const prc_item1 d, const S* __restrict__ s_tile, S* __restrict__ stage,
+                                               const uint16_t* __restrict__ srcl, const int32_t* __restrict__ ob,
+                                               S* __restrict__ val, const unsigned sink, const int wv, const int lane) {
+    constexpr int NST = prc_form_stores<S, FORM>::value;
+    const int nblocks = (d.g1 - d.g0) / PRC_BLK_GROUPS;
+    const int nsuper = nblocks / (PRC_WAVES * PRC_PAIR_DEPTH);
+    const prc_u32x4* in = (const prc_u32x4*) srcl + ((int64_t) d.g0 * (PRC_G / 8) + wv * 64 + lane);
+    const int32_t* obp = ob + (d.g0 + wv * PRC_BLK_GROUPS + (lane >> 2));
+    constexpr int64_t IN_STEP = PRC_PAIR_DEPTH * PRC_WAVES * 64;
+    constexpr int64_t OB_STEP = PRC_PAIR_DEPTH * PRC_WAVES * PRC_BLK_GROUPS;
+    if (nsuper > 0) {
+        prc_set A, B;
+#define PRC_PROCESS(t)                                                                  \
+    do {                                                                                \
+        prc_class_block<S, FORM>(s_tile, stage, (t).e0, (t).o0, val, sink, lane);       \
+        prc_class_block<S, FORM>(s_tile, stage, (t).e1, (t).o1, val, sink, lane);       \
+        prc_class_block<S, FORM>(s_tile, stage, (t).e2, (t).o2, val, sink, lane);       \
+        prc_class_block<S, FORM>(s_tile, stage, (t).e3, (t).o3, val, sink, lane);       \
+    } while (0)
+        prc_set_load(A, in, obp);
+        {
+            const int kn = 1 < nsuper ? 1 : 0;
+            prc_set_load(B, in + kn * IN_STEP, obp + kn * OB_STEP);
+        }
+        PRC_SET_WAIT_N(A, 8);
+        PRC_PROCESS(A);
+        int k = 1;
+#pragma unroll 1
+        for (; k + 1 < nsuper; k += 2) {
+            prc_set_load(A, in + (int64_t) (k + 1) * IN_STEP, obp + (int64_t) (k + 1) * OB_STEP);
+            PRC_SET_WAIT_N(B, 4 * NST + 8);   // the stores of the previous super-step + the 8 loads just issued
+            PRC_PROCESS(B);
+            const int kn = k + 2 < nsuper ? k + 2 : k + 1;
+            prc_set_load(B, in + (int64_t) kn * IN_STEP, obp + (int64_t) kn * OB_STEP);
+            PRC_SET_WAIT_N(A, 4 * NST + 8);
+            PRC_PROCESS(A);
+        }
+        PRC_SET_WAIT_N(B, 4 * NST);            // B: the last super-step, or a redundant copy of it (see prc_pair_item)
+        if (k < nsuper) PRC_PROCESS(B);
+#undef PRC_PROCESS
+    }
+    {   // the blocks left over (fewer than a super-step): the wave's up to four loads go out together
+        const int b0 = nsuper * (PRC_WAVES * PRC_PAIR_DEPTH);
+        prc_u32x4 cur[PRC_PAIR_DEPTH];
+        int32_t o[PRC_PAIR_DEPTH];
+#pragma unroll
+        for (int j = 0; j < PRC_PAIR_DEPTH; j++)
+            if (b0 + j * PRC_WAVES + wv < nblocks) {   // (wave-uniform)
+                const int64_t off = (int64_t) (b0 + j * PRC_WAVES);
+                cur[j] = __builtin_nontemporal_load(in + off * 64);
+                o[j] = __builtin_nontemporal_load(obp + off * PRC_BLK_GROUPS);
+            }
+#pragma unroll
+        for (int j = 0; j < PRC_PAIR_DEPTH; j++)
+            if (b0 + j * PRC_WAVES + wv < nblocks) prc_class_block<S, FORM>(s_tile, stage, cur[j], o[j], val, sink, lane);
+    }
+}
+
 // The edge form of one work item: every entry is an item.  A lane handles 4 consecutive entries of one group: one
 // 8-byte load, four LDS reads, one 16/32-byte store; 8 lanes cover a group, a wave 8 groups ("piece") per instruction.
 template <typename S>
@@ -621,14 +952,16 @@ __device__ __forceinline__ void prc_edge_item(const prc_item1 d, const S* __rest
     }
 }
 
-// Phase 1: one queue for both forms (item.form: 1 = pair, 0 = edge); the big pair items come first, the small
-// edge items of the cold tail fill the gaps at the end.
-template <typename S, int TILE>
+// Phase 1.  Two instantiations per element type, launched one after the other: CLASSED = true runs the class forms
+// (E1 .. H), CLASSED = false the generic pair form and the edge form (one kernel holding all of them needs more than the
+// 128 VGPRs a 1024-thread workgroup may have: the fp32 build spilled).  Each has its own work counter; the big items
+// come first, the small ones fill the gaps at the end.
+template <typename S, int TILE, bool CLASSED>
 __global__ void __launch_bounds__(PRC_THREADS)
 pr_cold_tile_kernel(const prc_item1* __restrict__ items, int n_items, unsigned int* __restrict__ queue,
                     const S* __restrict__ contrib, const int32_t* __restrict__ org, int nranks, int64_t span, int64_t slice, int64_t T,
                     const uint16_t* __restrict__ srcl, const int32_t* __restrict__ ob, S* __restrict__ val, unsigned sink_base,
-                    unsigned qbase) {
+                    unsigned qbase, const int32_t* __restrict__ vst) {
     __shared__ S s_tile[TILE];
     __shared__ S s_stage[PRC_WAVES][PRC_STAGE_BYTES / sizeof(S) + 64];   // + a dummy slot per lane
     __shared__ int s_item;
@@ -638,7 +971,7 @@ pr_cold_tile_kernel(const prc_item1* __restrict__ items, int n_items, unsigned i
     int loaded = -1;
     for (;;) {
         __syncthreads();   // everybody is done with s_item and the tile of the previous item
-        if (tid == 0) s_item = (int) (atomicAdd(&queue[PRC_Q1P], 1u) - qbase);
+        if (tid == 0) s_item = (int) (atomicAdd(&queue[CLASSED ? PRC_Q1E : PRC_Q1P], 1u) - qbase);
         __syncthreads();
         const int it = s_item;
         if ((unsigned) it >= (unsigned) n_items) break;   // (unsigned: a counter that ran away from the host's copy ends the kernel)
@@ -648,8 +981,26 @@ pr_cold_tile_kernel(const prc_item1* __restrict__ items, int n_items, unsigned i
             loaded = d.tile;
             __syncthreads();
         }
-        if (d.form) prc_pair_item<S>(d, s_tile, s_stage[wv], srcl, ob, val, sink, wv, lane);
-        else prc_edge_item<S>(d, s_tile, srcl, ob, val, wv, lane);
+        if constexpr (CLASSED) {
+            // the item is a run of groups of one tile: walk the class streams it crosses (stream c of tile t covers the
+            // groups [vst[8 t + c], vst[8 t + c + 1]); all bounds are multiples of a block)
+            const int32_t* vs = vst + ((int64_t) d.tile << PRC_CLS_BITS);
+            for (int cls = PRC_CL_E1; cls <= PRC_CL_H; cls++) {
+                const int32_t lo = max(d.g0, vs[cls]), hi = min(d.g1, vs[cls + 1]);
+                if (lo >= hi) continue;   // (workgroup-uniform)
+                const prc_item1 seg{d.tile, lo, hi, cls + 1};
+                switch (cls) {
+                case PRC_CL_E1: prc_class_item<S, PRC_FORM_E1>(seg, s_tile, s_stage[wv], srcl, ob, val, sink, wv, lane); break;
+                case PRC_CL_E2: prc_class_item<S, PRC_FORM_E2>(seg, s_tile, s_stage[wv], srcl, ob, val, sink, wv, lane); break;
+                case PRC_CL_E4: prc_class_item<S, PRC_FORM_E4>(seg, s_tile, s_stage[wv], srcl, ob, val, sink, wv, lane); break;
+                case PRC_CL_E8: prc_class_item<S, PRC_FORM_E8>(seg, s_tile, s_stage[wv], srcl, ob, val, sink, wv, lane); break;
+                default: prc_class_item<S, PRC_FORM_H>(seg, s_tile, s_stage[wv], srcl, ob, val, sink, wv, lane); break;
+                }
+            }
+        } else {
+            if (d.form == PRC_FORM_PAIR) prc_pair_item<S>(d, s_tile, s_stage[wv], srcl, ob, val, sink, wv, lane);
+            else prc_edge_item<S>(d, s_tile, srcl, ob, val, wv, lane);
+        }
     }
 }
 
@@ -858,10 +1209,11 @@ static int prc_upload_lists(pr_cold* c, const std::vector<uint8_t>* tile_class, 
     std::vector<prc_item1> l1;
     for (int k = 0; k < 2; k++) {
         c->o1[k] = (int64_t) l1.size();
-        for (int form = 1; form >= 0; form--) {
+        for (int part = 0; part < 3; part++) {   // class forms | generic pair form | edge form
+            if (part == 1) c->o1g[k] = (int64_t) l1.size();
             std::vector<prc_item1> a;
-            for (const prc_item1& it : (form ? c->h1p : c->h1e))
-                if ((tile_class ? (int) (*tile_class)[(size_t) it.tile] : 0) == k) a.push_back(it);
+            for (const prc_item1& it : (part < 2 ? c->h1p : c->h1e))
+                if ((tile_class ? (int) (*tile_class)[(size_t) it.tile] : 0) == k && (part == 2 || (part == 0) == (it.form >= PRC_FORM_E1))) a.push_back(it);
             std::stable_sort(a.begin(), a.end(), by_size1);
             l1.insert(l1.end(), a.begin(), a.end());
         }
@@ -966,6 +1318,18 @@ static hipError_t prc_exscan(const int32_t* in, int32_t* out, int64_t n, dbuf<ch
     return rocprim::exclusive_scan((void*) tmp.p, tb, in, out, 0, (size_t) n, rocprim::plus<int32_t>(), s);
 }
 
+// inclusive prefix sums of n int32 values (in != out)
+static hipError_t prc_inscan(const int32_t* in, int32_t* out, int64_t n, dbuf<char>& tmp, hipStream_t s) {
+    size_t tb = 0;
+    hipError_t e = rocprim::inclusive_scan(nullptr, tb, in, out, (size_t) n, rocprim::plus<int32_t>(), s);
+    if (e != hipSuccess) return e;
+    if (tmp.n < tb) {
+        tmp.release();
+        if (tmp.alloc(tb)) return hipErrorOutOfMemory;
+    }
+    return rocprim::inclusive_scan((void*) tmp.p, tb, in, out, (size_t) n, rocprim::plus<int32_t>(), s);
+}
+
 int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, hipStream_t s, pr_cold** outp) {
     *outp = nullptr;
     GMX_REQUIRE(prm.elem == 4 || prm.elem == 8, "pr cold: bad element size");
@@ -982,25 +1346,32 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
     c->ntiles = (c->ncold + tile_src - 1) / tile_src;
     c->nbins = (prm.nactive + c->binrows - 1) / c->binrows;
     if (c->nbins < 1) c->nbins = 1;
-    const int tilebits = gmx_bits_for(c->ntiles), binbits = gmx_bits_for(c->nbins);
+    const int tilebits = gmx_bits_for(c->ntiles), binbits = gmx_bits_for(c->nbins), vtbits = tilebits + PRC_CLS_BITS;
+    const int64_t nvt = c->ntiles << PRC_CLS_BITS;
     // an edge tile has pairs averaging fewer than this many edges (GMX_PR_COLD_PAIR_X100 overrides, in percent)
     const double pair_min = prc_env_int("GMX_PR_COLD_PAIR_X100", 125) / 100.0;
+    // a pair tile is stored in length classes when its (tile, bin) cells average at least this many edges (every
+    // (class, bin) sub-cell is padded to a group of 32 entries and 32 items).  Measured on RMAT-26 fp32, ms per step:
+    // 0 (round 2's generic form everywhere) 1.75, 1024 (80 tiles) 1.49, 256 (189 tiles) 1.46, 1 (all 343 pair tiles) 1.43
+    // -- the sub-cells stay fuller than feared (1.51 M -> 1.61 M cells), so every pair tile is classed by default.
+    const int64_t class_density = prc_env_int("GMX_PR_COLD_CLASS_DENSITY", 1);
     int st = GMX_OK;
     dbuf<uint64_t> k1, k2;
-    dbuf<int32_t> cflag, incl, nat, natpre, first, groups, c1raw, c1, ttab, delta, counts, id, order2, groups2, c2s, c2, tab2;
+    dbuf<int32_t> cflag, cincl, ps, pincl, pstart, plen, ppos, pos, endf, endpre, first, pfirst, groups, c1raw, c1, vtab, delta, counts, id, order2, groups2,
+        c2s, c2, tab2, tstat;
     dbuf<uint32_t> ckey, key2, key2s;
     dbuf<uint8_t> mode;
     dbuf<char> tmp;
-    const uint64_t* sk = nullptr;
-    std::vector<int32_t> ht, hdelta, tstart, h2;
+    uint64_t* sk = nullptr;
+    std::vector<int32_t> hts, hvt, hdelta, vstart, h2;
     std::vector<uint8_t> hmode;
     std::vector<prc_item1> v1p, v1e;
     std::vector<prc_item2> v2;
     std::vector<prc_item3> v3;
-    int64_t ngroups1 = 0, ngroups2 = 0, nc = 0, pair_edges = 0, pair_tiles = 0;
+    int64_t ngroups1 = 0, ngroups2 = 0, nc = 0, np = 0, pair_edges = 0, pair_tiles = 0, class_tiles = 0, class_edges = 0;
     hipDeviceProp_t prop;
     int dev = 0;
-    if (tilebits + binbits > 32) {
+    if (vtbits + binbits > 32) {
         gmx_set_error("pr cold: %lld tiles x %lld bins do not fit the sort key", (long long) c->ntiles, (long long) c->nbins);
         st = GMX_ERR_ARG;
         goto done;
@@ -1017,110 +1388,128 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
         *outp = c;
         return GMX_OK;
     }
-    {   // ---- (tile, bin, row, source) keys, sorted ----
+    {   // ---- (tile, [class,] bin, row, source) keys, sorted ----
         PRC_ALLOC(k1, Ec);
         PRC_ALLOC(k2, Ec);
         hipLaunchKernelGGL(prc_keys_kernel, dim3(prc_grid_for(Ec)), dim3(256), 0, s, keys, Ec, prm, tile_src, c->binrows, binbits, k1.p);
         rocprim::double_buffer<uint64_t> db(k1.p, k2.p);
         size_t tb = 0;
-        const unsigned end_bit = 32u + (unsigned) binbits + (unsigned) tilebits;
+        const unsigned end_bit = 32u + (unsigned) binbits + (unsigned) vtbits;
         PRC_TRY(rocprim::radix_sort_keys(nullptr, tb, db, (size_t) Ec, 0u, end_bit, s), "sort size");
         PRC_ALLOC(tmp, tb);
         PRC_TRY(rocprim::radix_sort_keys((void*) tmp.p, tb, db, (size_t) Ec, 0u, end_bit, s), "sort");
         PRC_TRY(hipStreamSynchronize(s), "sort sync");
         sk = db.current();
-        if (sk == k1.p) k2.release(); else k1.release();
     }
-    // ---- cells and natural pairs ----
     PRC_ALLOC(cflag, Ec + 1);
-    PRC_ALLOC(incl, Ec + 1);
-    PRC_ALLOC(nat, Ec + 1);
-    PRC_ALLOC(natpre, Ec + 1);
-    hipLaunchKernelGGL(prc_flag_kernel, dim3(prc_grid_for(Ec + 1)), dim3(256), 0, s, sk, Ec, cflag.p, nat.p);
-    {
-        size_t tb = 0;
-        PRC_TRY(rocprim::inclusive_scan(nullptr, tb, cflag.p, incl.p, (size_t) Ec, rocprim::plus<int32_t>(), s), "scan size");
-        if (tmp.n < tb) { tmp.release(); PRC_ALLOC(tmp, tb); }
-        PRC_TRY(rocprim::inclusive_scan((void*) tmp.p, tb, cflag.p, incl.p, (size_t) Ec, rocprim::plus<int32_t>(), s), "scan");
-        PRC_TRY(prc_exscan(nat.p, natpre.p, Ec + 1, tmp, s), "scan");
-        int32_t last = 0;
-        PRC_TRY(hipMemcpyAsync(&last, incl.p + (Ec - 1), 4, hipMemcpyDeviceToHost, s), "copy");
+    PRC_ALLOC(cincl, Ec + 1);
+    PRC_ALLOC(ps, Ec + 1);
+    PRC_ALLOC(pincl, Ec + 1);
+    PRC_ALLOC(mode, c->ntiles + 1);
+    PRC_ALLOC(tstat, 3 * (c->ntiles + 1));
+    hmode.assign((size_t) c->ntiles + 1, PRC_TM_EDGE);
+    for (int round = 0; round < 2; round++) {
+        // ---- cells ((virtual) tile, bin) and pairs ((virtual) tile, row): runs of the sorted keys ----
+        hipLaunchKernelGGL(prc_runs_kernel, dim3(prc_grid_for(Ec)), dim3(256), 0, s, (const uint64_t*) sk, Ec, cflag.p, ps.p);
+        PRC_TRY(prc_inscan(cflag.p, cincl.p, Ec, tmp, s), "scan");
+        PRC_TRY(prc_inscan(ps.p, pincl.p, Ec, tmp, s), "scan");
+        {
+            int32_t lastc = 0, lastp = 0;
+            PRC_TRY(hipMemcpyAsync(&lastc, cincl.p + (Ec - 1), 4, hipMemcpyDeviceToHost, s), "copy");
+            PRC_TRY(hipMemcpyAsync(&lastp, pincl.p + (Ec - 1), 4, hipMemcpyDeviceToHost, s), "copy");
+            PRC_TRY(hipStreamSynchronize(s), "sync");
+            c->ncells = nc = lastc;
+            np = lastp;
+        }
+        if (pstart.n < (size_t) np + 1) { pstart.release(); PRC_ALLOC(pstart, np + 1); }
+        hipLaunchKernelGGL(prc_pair_start_kernel, dim3(prc_grid_for(Ec + 1)), dim3(256), 0, s, (const int32_t*) ps.p, (const int32_t*) pincl.p, Ec, np, pstart.p);
+        if (round == 1) break;
+        // ---- per tile: edge form, generic pair form, or length classes ----
+        hipLaunchKernelGGL(prc_tile_stats_kernel, dim3(prc_grid_for(c->ntiles + 1)), dim3(256), 0, s, (const uint64_t*) sk, Ec,
+                           32 + binbits + PRC_CLS_BITS, c->ntiles, (const int32_t*) pincl.p, (const int32_t*) cincl.p, np, nc, tstat.p);
+        hts.resize((size_t) 3 * (c->ntiles + 1));
+        PRC_TRY(hipMemcpyAsync(hts.data(), tstat.p, sizeof(int32_t) * hts.size(), hipMemcpyDeviceToHost, s), "copy");
         PRC_TRY(hipStreamSynchronize(s), "sync");
-        c->ncells = nc = last;
+        for (int64_t t = 0; t < c->ntiles; t++) {
+            const int64_t ne = (int64_t) hts[3 * (t + 1)] - hts[3 * t], npt = (int64_t) hts[3 * (t + 1) + 1] - hts[3 * t + 1],
+                          nct = (int64_t) hts[3 * (t + 1) + 2] - hts[3 * t + 2];
+            hmode[t] = (npt > 0 && (double) ne >= pair_min * (double) npt) ? PRC_TM_PAIR : PRC_TM_EDGE;
+            if (hmode[t] == PRC_TM_PAIR) { pair_edges += ne; pair_tiles++; }
+            if (hmode[t] == PRC_TM_PAIR && class_density > 0 && ne >= class_density * nct) { hmode[t] = PRC_TM_CLASSED; class_tiles++; class_edges += ne; }
+        }
+        PRC_TRY(hipMemcpyAsync(mode.p, hmode.data(), hmode.size(), hipMemcpyHostToDevice, s), "copy");
+        if (class_tiles == 0) continue;   // (round 1 only re-derives what it already has: cheap next to the sort)
+        // ---- the pairs of the classed tiles move into their class's stream: stable sort on the (tile, class) field ----
+        hipLaunchKernelGGL(prc_class_kernel, dim3(prc_grid_for(Ec)), dim3(256), 0, s, sk, Ec, (const int32_t*) pincl.p, (const int32_t*) pstart.p,
+                           (const uint8_t*) mode.p, binbits);
+        {
+            uint64_t* other = sk == k1.p ? k2.p : k1.p;
+            rocprim::double_buffer<uint64_t> db(sk, other);
+            size_t tb = 0;
+            const unsigned b0 = 32u + (unsigned) binbits, b1 = b0 + (unsigned) vtbits;
+            PRC_TRY(rocprim::radix_sort_keys(nullptr, tb, db, (size_t) Ec, b0, b1, s), "sort size");
+            if (tmp.n < tb) { tmp.release(); PRC_ALLOC(tmp, tb); }
+            PRC_TRY(rocprim::radix_sort_keys((void*) tmp.p, tb, db, (size_t) Ec, b0, b1, s), "sort");
+            PRC_TRY(hipStreamSynchronize(s), "sort sync");
+            sk = db.current();
+        }
     }
+    if (sk == k1.p) k2.release(); else k1.release();
+    ps.release();
+    // ---- padded pair lengths -> stream offsets; cells; groups per cell ----
+    PRC_ALLOC(plen, np + 1);
+    PRC_ALLOC(ppos, np + 1);
+    hipLaunchKernelGGL(prc_pair_len_kernel, dim3(prc_grid_for(np + 1)), dim3(256), 0, s, (const uint64_t*) sk, (const int32_t*) pstart.p, np, binbits, plen.p);
+    PRC_TRY(prc_exscan(plen.p, ppos.p, np + 1, tmp, s), "scan");
+    plen.release();
     PRC_ALLOC(first, nc + 1);
+    PRC_ALLOC(pfirst, nc + 1);
     PRC_ALLOC(ckey, nc + 1);
     PRC_ALLOC(groups, nc + 1);
     PRC_ALLOC(c1raw, nc + 1);
     PRC_ALLOC(c1, nc + 1);
-    PRC_ALLOC(ttab, 4 * (c->ntiles + 1));
-    PRC_ALLOC(delta, c->ntiles + 1);
-    PRC_ALLOC(mode, c->ntiles + 1);
-    hipLaunchKernelGGL(prc_cell_first_kernel, dim3(prc_grid_for(Ec + 1)), dim3(256), 0, s, sk, (const int32_t*) cflag.p,
-                       (const int32_t*) incl.p, Ec, nc, first.p, ckey.p);
-    hipLaunchKernelGGL(prc_cell_groups_kernel, dim3(prc_grid_for(nc + 1)), dim3(256), 0, s, (const int32_t*) first.p,
-                       (const int32_t*) nullptr, nc, groups.p, (int32_t*) nullptr);
+    PRC_ALLOC(vtab, 2 * (nvt + 1));
+    PRC_ALLOC(delta, nvt + 1);
+    hipLaunchKernelGGL(prc_cell_first_kernel, dim3(prc_grid_for(Ec + 1)), dim3(256), 0, s, (const uint64_t*) sk, (const int32_t*) cflag.p,
+                       (const int32_t*) cincl.p, (const int32_t*) pincl.p, Ec, nc, np, first.p, pfirst.p, ckey.p);
+    hipLaunchKernelGGL(prc_cell_entry_groups_kernel, dim3(prc_grid_for(nc + 1)), dim3(256), 0, s, (const int32_t*) pfirst.p, (const int32_t*) ppos.p, nc, groups.p);
     PRC_TRY(prc_exscan(groups.p, c1raw.p, nc + 1, tmp, s), "scan");
-    hipLaunchKernelGGL(prc_tile_table_kernel, dim3(prc_grid_for(c->ntiles + 1)), dim3(256), 0, s, (const uint32_t*) ckey.p, nc,
-                       binbits, c->ntiles, (const int32_t*) c1raw.p, (const int32_t*) natpre.p, (const int32_t*) first.p, ttab.p);
-    ht.resize((size_t) 4 * (c->ntiles + 1));
-    PRC_TRY(hipMemcpyAsync(ht.data(), ttab.p, sizeof(int32_t) * ht.size(), hipMemcpyDeviceToHost, s), "copy");
+    hipLaunchKernelGGL(prc_vt_table_kernel, dim3(prc_grid_for(nvt + 1)), dim3(256), 0, s, (const uint32_t*) ckey.p, nc, binbits, nvt, (const int32_t*) c1raw.p, vtab.p);
+    hvt.resize((size_t) 2 * (nvt + 1));
+    PRC_TRY(hipMemcpyAsync(hvt.data(), vtab.p, sizeof(int32_t) * hvt.size(), hipMemcpyDeviceToHost, s), "copy");
     PRC_TRY(hipStreamSynchronize(s), "sync");
-    // ---- per tile: form (pair / edge) and start (on a block boundary) ----
-    hdelta.assign((size_t) c->ntiles + 1, 0);
-    tstart.assign((size_t) c->ntiles + 1, 0);
-    hmode.assign((size_t) c->ntiles + 1, 0);
-    for (int64_t t = 0; t < c->ntiles; t++) {
-        const int64_t g = (int64_t) ht[4 * (t + 1) + 1] - ht[4 * t + 1], np = (int64_t) ht[4 * (t + 1) + 2] - ht[4 * t + 2],
-                      ne = (int64_t) ht[4 * (t + 1) + 3] - ht[4 * t + 3];
-        hmode[t] = (np > 0 && (double) ne >= pair_min * (double) np) ? 1 : 0;
-        if (hmode[t]) { pair_edges += ne; pair_tiles++; }
-        hdelta[t] = tstart[t] - ht[4 * t + 1];
-        tstart[t + 1] = tstart[t] + (int32_t) ((g + PRC_SUPER_GROUPS - 1) / PRC_SUPER_GROUPS * PRC_SUPER_GROUPS);   // pair form: whole super-steps
+    cflag.release();
+    // ---- where the streams of the virtual tiles start: the generic pair form runs whole super-steps, every other
+    //      stream starts on a block boundary ----
+    hdelta.assign((size_t) nvt + 1, 0);
+    vstart.assign((size_t) nvt + 1, 0);
+    for (int64_t v = 0; v < nvt; v++) {
+        const int64_t g = (int64_t) hvt[2 * (v + 1) + 1] - hvt[2 * v + 1];
+        const bool generic_pair = (v & ((1 << PRC_CLS_BITS) - 1)) == PRC_CL_GEN && hmode[v >> PRC_CLS_BITS] == PRC_TM_PAIR;
+        const int64_t unit = generic_pair ? PRC_SUPER_GROUPS : PRC_BLK_GROUPS;
+        hdelta[v] = vstart[v] - hvt[2 * v + 1];
+        const int64_t nxt = (int64_t) vstart[v] + (g + unit - 1) / unit * unit;
+        if (nxt * PRC_G >= (1LL << 31)) {
+            gmx_set_error("pr cold: %lld padded entries exceed int32", (long long) (nxt * PRC_G));
+            st = GMX_ERR_ARG;
+            goto done;
+        }
+        vstart[v + 1] = (int32_t) nxt;
     }
-    ngroups1 = tstart[c->ntiles];
-    if (ngroups1 * PRC_G >= (1LL << 31)) {
-        gmx_set_error("pr cold: %lld padded entries exceed int32", (long long) (ngroups1 * PRC_G));
-        st = GMX_ERR_ARG;
-        goto done;
-    }
+    ngroups1 = vstart[nvt];
     c->P1 = ngroups1 * PRC_G;
     PRC_TRY(hipMemcpyAsync(delta.p, hdelta.data(), sizeof(int32_t) * hdelta.size(), hipMemcpyHostToDevice, s), "copy");
-    PRC_TRY(hipMemcpyAsync(mode.p, hmode.data(), hmode.size(), hipMemcpyHostToDevice, s), "copy");
     hipLaunchKernelGGL(prc_cell_start_kernel, dim3(prc_grid_for(nc)), dim3(256), 0, s, (const int32_t*) c1raw.p,
                        (const uint32_t*) ckey.p, binbits, (const int32_t*) delta.p, nc, c1.p);
-    // ---- final pair ends, items per cell, bin-major order ----
-    hipLaunchKernelGGL(prc_final_flag_kernel, dim3(prc_grid_for(Ec)), dim3(256), 0, s, (const int32_t*) incl.p,
-                       (const int32_t*) first.p, (const int32_t*) c1.p, (const uint32_t*) ckey.p, binbits,
-                       (const uint8_t*) mode.p, Ec, nat.p);
-    PRC_TRY(prc_exscan(nat.p, natpre.p, Ec + 1, tmp, s), "scan");   // natpre: pair ends before an edge
-    if (prc_env_int("GMX_PR_DEBUG", 0) >= 2) {
-        int32_t np = 0;
-        PRC_TRY(hipMemcpyAsync(&np, natpre.p + Ec, 4, hipMemcpyDeviceToHost, s), "copy");
-        PRC_TRY(hipStreamSynchronize(s), "sync");
-        dbuf<int32_t> len;
-        dbuf<unsigned long long> hist;
-        PRC_ALLOC(len, (size_t) np + 1);
-        PRC_ALLOC(hist, 32);
-        PRC_TRY(hipMemsetAsync(len.p, 0, sizeof(int32_t) * ((size_t) np + 1), s), "memset");
-        PRC_TRY(hipMemsetAsync(hist.p, 0, sizeof(unsigned long long) * 32, s), "memset");
-        hipLaunchKernelGGL(prc_dbg_pair_len_kernel, dim3(prc_grid_for(Ec)), dim3(256), 0, s, (const int32_t*) natpre.p, Ec, len.p);
-        hipLaunchKernelGGL(prc_dbg_len_hist_kernel, dim3(prc_grid_for(np)), dim3(256), 0, s, (const int32_t*) len.p, (int64_t) np, hist.p);
-        unsigned long long hh[32];
-        PRC_TRY(hipMemcpyAsync(hh, hist.p, sizeof(hh), hipMemcpyDeviceToHost, s), "copy");
-        PRC_TRY(hipStreamSynchronize(s), "sync");
-        fprintf(stderr, "gmx pr cold: pair lengths (all tiles, after the cuts): bucket <= 2^b : pairs / edges\n");
-        for (int b = 0; b < 16; b++)
-            if (hh[2 * b]) fprintf(stderr, "   <= %5d : %12llu / %12llu\n", 1 << b, hh[2 * b], hh[2 * b + 1]);
-        fprintf(stderr, "gmx pr cold: per tile (first 48, then every 64th): tile form groups pairs edges edges/pair\n");
-        for (int64_t t = 0; t < c->ntiles; t++) {
-            if (t >= 48 && t % 64) continue;
-            const int64_t g = (int64_t) ht[4 * (t + 1) + 1] - ht[4 * t + 1], npt = (int64_t) ht[4 * (t + 1) + 2] - ht[4 * t + 2],
-                          ne = (int64_t) ht[4 * (t + 1) + 3] - ht[4 * t + 3];
-            fprintf(stderr, "   %5lld %d %9lld %9lld %10lld %.2f\n", (long long) t, (int) hmode[t], (long long) g, (long long) npt, (long long) ne,
-                    npt ? (double) ne / (double) npt : 0.0);
-        }
-    }
+    // ---- entry positions, item ends, items per cell, bin-major order ----
+    PRC_ALLOC(pos, Ec);
+    PRC_ALLOC(endf, Ec + 1);
+    PRC_ALLOC(endpre, Ec + 1);
+    hipLaunchKernelGGL(prc_pos_end_kernel, dim3(prc_grid_for(Ec + 1)), dim3(256), 0, s, (const uint64_t*) sk, (const int32_t*) cincl.p,
+                       (const int32_t*) pincl.p, (const int32_t*) pstart.p, (const int32_t*) ppos.p, (const int32_t*) pfirst.p,
+                       (const int32_t*) c1.p, (const uint8_t*) mode.p, binbits, prm.elem, Ec, pos.p, endf.p);
+    PRC_TRY(prc_exscan(endf.p, endpre.p, Ec + 1, tmp, s), "scan");   // endpre: item ends before an edge
+    pincl.release();
     PRC_ALLOC(counts, nc + 1);
     PRC_ALLOC(key2, nc);
     PRC_ALLOC(key2s, nc);
@@ -1130,14 +1519,14 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
     PRC_ALLOC(c2s, nc + 1);
     PRC_ALLOC(c2, nc);
     hipLaunchKernelGGL(prc_cell_groups_kernel, dim3(prc_grid_for(nc + 1)), dim3(256), 0, s, (const int32_t*) first.p,
-                       (const int32_t*) natpre.p, nc, groups.p, counts.p);
+                       (const int32_t*) endpre.p, nc, groups.p, counts.p);
     hipLaunchKernelGGL(prc_cell_key2_kernel, dim3(prc_grid_for(nc)), dim3(256), 0, s, (const uint32_t*) ckey.p, nc, binbits,
-                       tilebits, key2.p, id.p);
+                       vtbits, key2.p, id.p);
     {
         size_t tb = 0;
-        PRC_TRY(rocprim::radix_sort_pairs(nullptr, tb, key2.p, key2s.p, id.p, order2.p, (size_t) nc, 0u, (unsigned) (binbits + tilebits), s), "sort size");
+        PRC_TRY(rocprim::radix_sort_pairs(nullptr, tb, key2.p, key2s.p, id.p, order2.p, (size_t) nc, 0u, (unsigned) (binbits + vtbits), s), "sort size");
         if (tmp.n < tb) { tmp.release(); PRC_ALLOC(tmp, tb); }
-        PRC_TRY(rocprim::radix_sort_pairs((void*) tmp.p, tb, key2.p, key2s.p, id.p, order2.p, (size_t) nc, 0u, (unsigned) (binbits + tilebits), s), "sort");
+        PRC_TRY(rocprim::radix_sort_pairs((void*) tmp.p, tb, key2.p, key2s.p, id.p, order2.p, (size_t) nc, 0u, (unsigned) (binbits + vtbits), s), "sort");
     }
     PRC_TRY(hipMemsetAsync(groups2.p + nc, 0, sizeof(int32_t), s), "memset");
     hipLaunchKernelGGL(prc_gather_i32_kernel, dim3(prc_grid_for(nc)), dim3(256), 0, s, (const int32_t*) groups.p,
@@ -1146,14 +1535,14 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
     hipLaunchKernelGGL(prc_scatter_i32_kernel, dim3(prc_grid_for(nc)), dim3(256), 0, s, (const int32_t*) c2s.p,
                        (const int32_t*) order2.p, nc, c2.p);
     {
-        int32_t tot = 0, np = 0;
+        int32_t tot = 0, ni = 0;
         PRC_TRY(hipMemcpyAsync(&tot, c2s.p + nc, 4, hipMemcpyDeviceToHost, s), "copy");
-        PRC_TRY(hipMemcpyAsync(&np, natpre.p + Ec, 4, hipMemcpyDeviceToHost, s), "copy");
+        PRC_TRY(hipMemcpyAsync(&ni, endpre.p + Ec, 4, hipMemcpyDeviceToHost, s), "copy");
         PRC_TRY(hipStreamSynchronize(s), "sync");
         ngroups2 = tot;
-        c->npairs = np;
+        c->npairs = ni;
     }
-    if (ngroups2 * PRC_G >= (1LL << 31)) {
+    if (ngroups2 * PRC_G >= (1LL << 31) - (int64_t) c->grid * PRC_THREADS) {
         gmx_set_error("pr cold: %lld padded items exceed int32", (long long) (ngroups2 * PRC_G));
         st = GMX_ERR_ARG;
         goto done;
@@ -1163,18 +1552,19 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
     PRC_ALLOC(c->srcl, c->P1);
     PRC_ALLOC(c->ob, ngroups1);
     PRC_ALLOC(c->rowl, c->P2);
-    PRC_ALLOC(c->val, ((size_t) c->P2 + (size_t) c->grid * PRC_THREADS) * prm.elem);   // + the sink slots of the pair kernel
+    PRC_ALLOC(c->val, ((size_t) c->P2 + (size_t) c->grid * PRC_THREADS) * prm.elem);   // + the sink slots behind the items
     hipLaunchKernelGGL(prc_fill_u16_kernel, dim3(prc_grid_for(c->P1)), dim3(256), 0, s, c->srcl.p, c->P1, (uint16_t) tile_src);
     PRC_TRY(hipMemsetAsync(c->rowl.p, 0xff, (size_t) c->P2 * 2, s), "memset");
     PRC_TRY(hipMemsetAsync(c->val.p, 0, ((size_t) c->P2 + (size_t) c->grid * PRC_THREADS) * prm.elem, s), "memset");
-    hipLaunchKernelGGL(prc_fill_items_kernel, dim3(prc_grid_for(Ec)), dim3(256), 0, s, sk, (const int32_t*) incl.p,
-                       (const int32_t*) first.p, (const int32_t*) c1.p, (const int32_t*) c2.p, (const int32_t*) nat.p,
-                       (const int32_t*) natpre.p, Ec, c->srcl.p, c->rowl.p);
-    hipLaunchKernelGGL(prc_fill_ob_kernel, dim3(prc_grid_for(ngroups1)), dim3(256), 0, s, (const int32_t*) c1.p,
-                       (const int32_t*) c2.p, (const int32_t*) first.p, (const int32_t*) natpre.p, nc, ngroups1, c->ob.p);
+    hipLaunchKernelGGL(prc_fill_items_kernel, dim3(prc_grid_for(Ec)), dim3(256), 0, s, (const uint64_t*) sk, (const int32_t*) cincl.p,
+                       (const int32_t*) first.p, (const int32_t*) pos.p, (const int32_t*) c2.p, (const int32_t*) endf.p,
+                       (const int32_t*) endpre.p, binbits, (uint16_t) tile_src, Ec, c->srcl.p, c->rowl.p);
+    hipLaunchKernelGGL(prc_fill_ob_kernel, dim3(prc_grid_for(ngroups1)), dim3(256), 0, s, (const int32_t*) c1.p, (const int32_t*) c2.p,
+                       (const int32_t*) first.p, (const int32_t*) pfirst.p, (const int32_t*) pstart.p, (const int32_t*) ppos.p,
+                       (const int32_t*) endpre.p, (const uint32_t*) ckey.p, binbits, nc, ngroups1, (int32_t) c->P2, c->ob.p);
     PRC_ALLOC(tab2, c->nbins + 1);
     hipLaunchKernelGGL(prc_bin_table_kernel, dim3(prc_grid_for(c->nbins + 1)), dim3(256), 0, s, (const uint32_t*) key2s.p,
-                       (const int32_t*) c2s.p, nc, tilebits, ngroups2, c->nbins, tab2.p);
+                       (const int32_t*) c2s.p, nc, vtbits, ngroups2, c->nbins, tab2.p);
     h2.resize((size_t) c->nbins + 1);
     PRC_TRY(hipMemcpyAsync(h2.data(), tab2.p, sizeof(int32_t) * h2.size(), hipMemcpyDeviceToHost, s), "copy");
     PRC_TRY(hipStreamSynchronize(s), "sync");
@@ -1222,12 +1612,22 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
         // a bin is split when it exceeds thr2 (a split costs its accumulators written and read again)
         const int64_t thr2 = (int64_t) ch2 * prc_env_int("GMX_PR_COLD_SPLIT_X100", 300) / 100;
         for (int64_t t = 0; t < c->ntiles; t++) {
-            const int32_t g0 = tstart[t];
-            // pair tiles run whole blocks (the padding behind the last cell ends no pair); edge tiles stop at the
-            // last real group (an entry there would be stored)
-            const int32_t g1 = hmode[t] ? tstart[t + 1] : g0 + (ht[4 * (t + 1) + 1] - ht[4 * t + 1]);
-            for (int32_t g = g0; g < g1; g += ch1) (hmode[t] ? v1p : v1e).push_back({(int32_t) t, g, std::min(g1, g + ch1), hmode[t] ? 1 : 0});
+            const int64_t v0 = t << PRC_CLS_BITS;
+            if (hmode[t] == PRC_TM_CLASSED) {   // one run of groups over all class streams of the tile (whole blocks; the padding ends no item)
+                const int32_t g0 = vstart[v0 + PRC_CL_E1], g1 = vstart[v0 + PRC_CL_H + 1];
+                for (int32_t g = g0; g < g1; g += ch1) v1p.push_back({(int32_t) t, g, std::min(g1, g + ch1), PRC_FORM_TILE});
+                continue;
+            }
+            const int32_t graw = hvt[2 * (v0 + 1) + 1] - hvt[2 * v0 + 1];
+            if (graw == 0) continue;
+            const int32_t g0 = vstart[v0];
+            const int form = hmode[t] == PRC_TM_PAIR ? PRC_FORM_PAIR : PRC_FORM_EDGE;
+            // pair tiles run whole super-steps; edge tiles stop at the last real group (an entry there would be stored)
+            const int32_t g1 = form == PRC_FORM_PAIR ? vstart[v0 + 1] : g0 + graw;
+            for (int32_t g = g0; g < g1; g += ch1) (form == PRC_FORM_EDGE ? v1e : v1p).push_back({(int32_t) t, g, std::min(g1, g + ch1), form});
         }
+        PRC_ALLOC(c->vstart, vstart.size());
+        PRC_TRY(hipMemcpy(c->vstart.p, vstart.data(), sizeof(int32_t) * vstart.size(), hipMemcpyHostToDevice), "copy");
         int32_t slot = 0;
         c->all_bins = true;
         for (int64_t b = 0; b < c->nbins; b++) {
@@ -1268,13 +1668,16 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
                 (long long) bs.front(), (long long) bs[bs.size() / 2], (long long) bs[bs.size() * 9 / 10], (long long) bs.back(),
                 (long long) over[0], (long long) over[1], (long long) over[2], (long long) over[3], (long long) sum_over[0],
                 (long long) sum_over[1], (long long) sum_over[2], (long long) sum_over[3]);
-    }
-    if (getenv("GMX_PR_DEBUG"))
-        fprintf(stderr, "gmx pr cold: T %lld, %lld edges -> %lld entries in %lld cells (%lld tiles x %lld bins); %lld pair tiles with %lld edges; "
-                "%lld pairs -> %lld items; work items %lld + %lld / %lld / %lld, %lld slots, lo_bits %d\n", (long long) prm.T, (long long) Ec,
+        int64_t cg[1 << PRC_CLS_BITS] = {0};
+        for (int64_t v = 0; v < nvt; v++) cg[v & ((1 << PRC_CLS_BITS) - 1)] += (int64_t) vstart[v + 1] - vstart[v];
+        fprintf(stderr, "gmx pr cold: T %lld, %lld edges -> %lld entries in %lld cells (%lld tiles x %lld bins); %lld pair tiles with %lld edges, of them %lld "
+                "in length classes with %lld edges; groups by class generic/E1/E2/E4/E8/H %lld/%lld/%lld/%lld/%lld/%lld; %lld natural pairs -> %lld item ends -> "
+                "%lld items; work items %lld + %lld / %lld / %lld, %lld slots, lo_bits %d\n", (long long) prm.T, (long long) Ec,
                 (long long) c->P1, (long long) nc, (long long) c->ntiles, (long long) c->nbins, (long long) pair_tiles, (long long) pair_edges,
-                (long long) c->npairs, (long long) c->P2, (long long) c->n1p, (long long) c->n1e, (long long) c->n2, (long long) c->n3,
-                (long long) c->nslots, c->lo_bits);
+                (long long) class_tiles, (long long) class_edges, (long long) cg[0], (long long) cg[1], (long long) cg[2], (long long) cg[3],
+                (long long) cg[4], (long long) cg[5], (long long) np, (long long) c->npairs, (long long) c->P2, (long long) c->n1p,
+                (long long) c->n1e, (long long) c->n2, (long long) c->n3, (long long) c->nslots, c->lo_bits);
+    }
 done:
     if (st != GMX_OK) {
         delete c;
@@ -1290,18 +1693,28 @@ const void* pr_cold_partial(const pr_cold* c) { return c ? (const void*) c->cold
 int64_t pr_cold_edges(const pr_cold* c) { return c ? c->Ec : 0; }
 int64_t pr_cold_items(const pr_cold* c) { return c ? c->P2 : 0; }
 
-// phase 1 over the tile classes [k0, k1)
+// phase 1 over the tile classes [k0, k1): per class the class-form items, then the generic pair / edge items
 template <typename S>
 static void prc_gather(pr_cold* c, const void* contrib, int k0, int k1, hipStream_t s) {
     constexpr int TILE = prc_tile_elems((int) sizeof(S));
     const int64_t span = c->prm.slice - c->prm.T;
-    const int64_t n = c->o1[k1] - c->o1[k0];
-    if (n <= 0) return;
-    const unsigned grid = (unsigned) std::min<int64_t>(c->grid, n);
-    hipLaunchKernelGGL((pr_cold_tile_kernel<S, TILE>), dim3(grid), dim3(PRC_THREADS), 0, s,
-                       (const prc_item1*) c->it1p.p + c->o1[k0], (int) n, c->queue.p, (const S*) contrib, (const int32_t*) c->torg.p, c->prm.nranks, span, c->prm.slice,
-                       c->prm.T, (const uint16_t*) c->srcl.p, (const int32_t*) c->ob.p, (S*) c->val.p, (unsigned) c->P2, c->q1);
-    c->q1 += (uint32_t) n + grid;   // every workgroup claims until its first miss
+    for (int k = k0; k < k1; k++) {
+        const int64_t nc = c->o1g[k] - c->o1[k], ng = c->o1[k + 1] - c->o1g[k];
+        if (nc > 0) {
+            const unsigned grid = (unsigned) std::min<int64_t>(c->grid, nc);
+            hipLaunchKernelGGL((pr_cold_tile_kernel<S, TILE, true>), dim3(grid), dim3(PRC_THREADS), 0, s,
+                               (const prc_item1*) c->it1p.p + c->o1[k], (int) nc, c->queue.p, (const S*) contrib, (const int32_t*) c->torg.p, c->prm.nranks, span,
+                               c->prm.slice, c->prm.T, (const uint16_t*) c->srcl.p, (const int32_t*) c->ob.p, (S*) c->val.p, (unsigned) c->P2, c->q1c, (const int32_t*) c->vstart.p);
+            c->q1c += (uint32_t) nc + grid;   // every workgroup claims until its first miss
+        }
+        if (ng > 0) {
+            const unsigned grid = (unsigned) std::min<int64_t>(c->grid, ng);
+            hipLaunchKernelGGL((pr_cold_tile_kernel<S, TILE, false>), dim3(grid), dim3(PRC_THREADS), 0, s,
+                               (const prc_item1*) c->it1p.p + c->o1g[k], (int) ng, c->queue.p, (const S*) contrib, (const int32_t*) c->torg.p, c->prm.nranks, span,
+                               c->prm.slice, c->prm.T, (const uint16_t*) c->srcl.p, (const int32_t*) c->ob.p, (S*) c->val.p, (unsigned) c->P2, c->q1, (const int32_t*) c->vstart.p);
+            c->q1 += (uint32_t) ng + grid;
+        }
+    }
 }
 
 // phases 2 and 3 of part q

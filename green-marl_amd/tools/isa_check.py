@@ -153,28 +153,17 @@ def parse(body):
 def check_kernel(body):
     """-> (errors, stats)"""
     blocks = parse(body)
-    # Logical prefetch sets: asm loads whose destination registers overlap load the same set (the compiler may give an
-    # asm statement's scalar outputs other registers than its twin elsewhere in the loop -- every statement defines
-    # its outputs anew).  What is "in flight" is the register list of the statement that ran last.
+    # Every asm load STATEMENT is tracked on its own (the kernel has one two-set pipeline per work-item form, and the
+    # register allocator reuses the same registers across forms): what a statement has "in flight" is the part of its
+    # destination registers that no later asm load has overwritten.
     loads = [ins for b in blocks for ins in b["ins"] if ins.kind == "L"]
     if not loads:
         return ["no inline-asm prefetch found"], {}
-    comp = list(range(len(loads)))
-
-    def find(x):
-        while comp[x] != x:
-            x = comp[x]
-        return x
-    for a in range(len(loads)):
-        for c in range(a + 1, len(loads)):
-            if loads[a].regs & loads[c].regs:
-                comp[find(c)] = find(a)
-    roots = sorted({find(x) for x in range(len(loads))})
-    set_of = {id(ins): roots.index(find(i)) for i, ins in enumerate(loads)}
-    nset = len(roots)
-    # state per block entry: per set (VMEM operations issued since its load, landed?, registers of that load); None = unreached
+    lid = {id(ins): i for i, ins in enumerate(loads)}
+    nl = len(loads)
+    # state per block entry: per load statement (VMEM operations issued since it, landed?, registers still its own); None = unreached
     entry = [None] * len(blocks)
-    entry[0] = [(INF, True, frozenset())] * nset
+    entry[0] = [(INF, True, frozenset())] * nl
     errors, waits = [], {}
     work = [0]
 
@@ -182,8 +171,8 @@ def check_kernel(body):
         st = list(entry[i])
         for ins in blocks[i]["ins"]:
             if ins.kind == "L":
-                k = set_of[id(ins)]
-                st = [(min(CAP, c + ins.n) if c < INF else INF, r, g) for (c, r, g) in st]
+                k = lid[id(ins)]
+                st = [(min(CAP, c + ins.n) if c < INF else INF, r, g - ins.regs) for (c, r, g) in st]
                 st[k] = (0, False, ins.regs)
             elif ins.kind == "W":
                 st = [(c, r or (c < INF and c >= ins.n), g) for (c, r, g) in st]
@@ -216,7 +205,7 @@ def check_kernel(body):
             flow(i, True)
     if any(re.match(r"scratch_", ins.text) for b in blocks for ins in b["ins"]):
         errors.append("scratch instructions present")
-    stats = {"prefetch_sets": nset, "asm_loads": len(loads), "waits": waits,
+    stats = {"asm_loads": nl, "waits": waits,
              "stores": sum(ins.text.startswith("global_store") for b in blocks for ins in b["ins"])}
     return errors, stats
 
