@@ -52,6 +52,12 @@
 #define PRC_LDS_LIMIT 163840     // LDS of a CU
 // elements of the contribution tile of phase 1: what the 16 stages (+ a dummy slot per lane) and a few words leave
 static constexpr int prc_tile_elems(int elem) { return (PRC_LDS_LIMIT - 16 * (PRC_STAGE_BYTES + 64 * elem) - 64) / elem; }
+// ... of a plan stored in length classes throughout: the only staging left is class H's 64 results per wave, so the tile
+// takes the rest of the LDS, up to what a 15-bit source number reaches (fp32: 32768, fp64: 19448 -- a quarter fewer
+// tiles, cells and pairs than with the generic form's tile)
+static constexpr int prc_tile_elems_classed(int elem) {
+    return (PRC_LDS_LIMIT - 16 * 64 * elem - 64) / elem < 32768 ? (PRC_LDS_LIMIT - 16 * 64 * elem - 64) / elem / 8 * 8 : 32768;
+}
 #define PRC_THREADS 1024
 #define PRC_WAVES (PRC_THREADS / 64)
 #define PRC_UNROLL 4             // pieces (8 groups = 256 items) a wave keeps in flight
@@ -85,7 +91,7 @@ static constexpr int prc_tile_elems(int elem) { return (PRC_LDS_LIMIT - 16 * (PR
 enum { PRC_CL_GEN = 0, PRC_CL_E1 = 1, PRC_CL_E2 = 2, PRC_CL_E4 = 3, PRC_CL_E8 = 4, PRC_CL_H = 5 };
 enum { PRC_FORM_EDGE = 0, PRC_FORM_PAIR = 1, PRC_FORM_E1 = 2, PRC_FORM_E2 = 3, PRC_FORM_E4 = 4, PRC_FORM_E8 = 5, PRC_FORM_H = 6,
        PRC_FORM_TILE = 7 };   // TILE: a run of groups of a classed tile; the class streams it crosses come from the stream table
-enum { PRC_TM_EDGE = 0, PRC_TM_PAIR = 1, PRC_TM_CLASSED = 2 };   // how a tile is stored
+enum { PRC_TM_EDGE = 0, PRC_TM_PAIR = 1, PRC_TM_CLASSED = 2, PRC_TM_SINGLES = 3 };   // how a tile is stored (SINGLES: every edge an item, as class E1)
 __host__ __device__ static inline int prc_class_of_len(int len) { return len <= 1 ? PRC_CL_E1 : len == 2 ? PRC_CL_E2 : len <= 4 ? PRC_CL_E4 : len <= 8 ? PRC_CL_E8 : PRC_CL_H; }
 __host__ __device__ static inline int prc_padded_len(int cls, int len) {
     return cls == PRC_CL_GEN ? len : cls == PRC_CL_H ? (len + 7) & ~7 : 1 << (cls - 1);
@@ -176,12 +182,14 @@ __global__ void prc_keys_kernel(const uint64_t* __restrict__ keys, int64_t n, pr
 }
 
 // cflag: first edge of a cell (same virtual tile and bin).  ps: first edge of a (virtual tile, row) pair.  n entries each.
-__global__ void prc_runs_kernel(const uint64_t* __restrict__ k, int64_t n, int32_t* __restrict__ cflag, int32_t* __restrict__ ps) {
+// `single` (optional): the tile modes; in PRC_TM_SINGLES tiles every edge is a pair of its own (edge tiles stored as class E1).
+__global__ void prc_runs_kernel(const uint64_t* __restrict__ k, int64_t n, const uint8_t* __restrict__ single, int tshift,
+                                int32_t* __restrict__ cflag, int32_t* __restrict__ ps) {
     int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         cflag[i] = (i == 0 || (k[i] >> 32) != (k[i - 1] >> 32)) ? 1 : 0;
-        ps[i] = (i == 0 || (k[i] >> 16) != (k[i - 1] >> 16)) ? 1 : 0;
+        ps[i] = (i == 0 || (k[i] >> 16) != (k[i - 1] >> 16) || (single && single[k[i] >> tshift] == PRC_TM_SINGLES)) ? 1 : 0;
     }
 }
 
@@ -220,7 +228,9 @@ __global__ void prc_class_kernel(uint64_t* __restrict__ k, int64_t n, const int3
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         const uint64_t key = k[i];
-        if (mode[key >> (32 + binbits + PRC_CLS_BITS)] != PRC_TM_CLASSED) continue;
+        const int m = mode[key >> (32 + binbits + PRC_CLS_BITS)];
+        if (m == PRC_TM_SINGLES) { k[i] = key | ((uint64_t) PRC_CL_E1 << (32 + binbits)); continue; }
+        if (m != PRC_TM_CLASSED) continue;
         const int32_t p = pincl[i] - 1;
         k[i] = key | ((uint64_t) prc_class_of_len(pstart[p + 1] - pstart[p]) << (32 + binbits));
     }
@@ -963,7 +973,7 @@ pr_cold_tile_kernel(const prc_item1* __restrict__ items, int n_items, unsigned i
                     const uint16_t* __restrict__ srcl, const int32_t* __restrict__ ob, S* __restrict__ val, unsigned sink_base,
                     unsigned qbase, const int32_t* __restrict__ vst) {
     __shared__ S s_tile[TILE];
-    __shared__ S s_stage[PRC_WAVES][PRC_STAGE_BYTES / sizeof(S) + 64];   // + a dummy slot per lane
+    __shared__ S s_stage[PRC_WAVES][CLASSED ? 64 : PRC_STAGE_BYTES / sizeof(S) + 64];   // generic form: + a dummy slot per lane
     __shared__ int s_item;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1338,7 +1348,12 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
     pr_cold* c = new pr_cold();
     c->prm = prm;
     c->Ec = Ec;
-    c->tile = prc_tile_elems(prm.elem);
+    // GMX_PR_COLD_CLASS_DENSITY: 1 (default) = every tile in length classes (pair tiles by pair length, edge tiles as
+    // class E1) with the larger tile that leaves; 0 = round 2's generic pair / edge forms; n > 1 = classes only for the
+    // pair tiles whose (tile, bin) cells average >= n edges, the generic forms for the rest (development)
+    const int64_t class_density = prc_env_int("GMX_PR_COLD_CLASS_DENSITY", 1);
+    const bool all_classed = class_density == 1;
+    c->tile = all_classed ? prc_tile_elems_classed(prm.elem) : prc_tile_elems(prm.elem);
     const int tile_src = c->tile - 1;
     c->limbs = prm.elem == 4 ? 1 : 2;
     c->binrows = PRC_LDS_BYTES / 8 / c->limbs;
@@ -1350,11 +1365,8 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
     const int64_t nvt = c->ntiles << PRC_CLS_BITS;
     // an edge tile has pairs averaging fewer than this many edges (GMX_PR_COLD_PAIR_X100 overrides, in percent)
     const double pair_min = prc_env_int("GMX_PR_COLD_PAIR_X100", 125) / 100.0;
-    // a pair tile is stored in length classes when its (tile, bin) cells average at least this many edges (every
-    // (class, bin) sub-cell is padded to a group of 32 entries and 32 items).  Measured on RMAT-26 fp32, ms per step:
-    // 0 (round 2's generic form everywhere) 1.75, 1024 (80 tiles) 1.49, 256 (189 tiles) 1.46, 1 (all 343 pair tiles) 1.43
-    // -- the sub-cells stay fuller than feared (1.51 M -> 1.61 M cells), so every pair tile is classed by default.
-    const int64_t class_density = prc_env_int("GMX_PR_COLD_CLASS_DENSITY", 1);
+    // (measured on RMAT-26 fp32 with the generic form's tile, ms per step: density 0 -> 1.75, 1024 (80 tiles classed) -> 1.49,
+    // 256 (189 tiles) -> 1.46, every pair tile -> 1.43: the (class, bin) sub-cells stay fuller than feared, 1.51 M -> 1.61 M cells)
     int st = GMX_OK;
     dbuf<uint64_t> k1, k2;
     dbuf<int32_t> cflag, cincl, ps, pincl, pstart, plen, ppos, pos, endf, endpre, first, pfirst, groups, c1raw, c1, vtab, delta, counts, id, order2, groups2,
@@ -1410,7 +1422,8 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
     hmode.assign((size_t) c->ntiles + 1, PRC_TM_EDGE);
     for (int round = 0; round < 2; round++) {
         // ---- cells ((virtual) tile, bin) and pairs ((virtual) tile, row): runs of the sorted keys ----
-        hipLaunchKernelGGL(prc_runs_kernel, dim3(prc_grid_for(Ec)), dim3(256), 0, s, (const uint64_t*) sk, Ec, cflag.p, ps.p);
+        hipLaunchKernelGGL(prc_runs_kernel, dim3(prc_grid_for(Ec)), dim3(256), 0, s, (const uint64_t*) sk, Ec,
+                           round ? (const uint8_t*) mode.p : (const uint8_t*) nullptr, 32 + binbits + PRC_CLS_BITS, cflag.p, ps.p);
         PRC_TRY(prc_inscan(cflag.p, cincl.p, Ec, tmp, s), "scan");
         PRC_TRY(prc_inscan(ps.p, pincl.p, Ec, tmp, s), "scan");
         {
@@ -1436,6 +1449,7 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
             hmode[t] = (npt > 0 && (double) ne >= pair_min * (double) npt) ? PRC_TM_PAIR : PRC_TM_EDGE;
             if (hmode[t] == PRC_TM_PAIR) { pair_edges += ne; pair_tiles++; }
             if (hmode[t] == PRC_TM_PAIR && class_density > 0 && ne >= class_density * nct) { hmode[t] = PRC_TM_CLASSED; class_tiles++; class_edges += ne; }
+            else if (hmode[t] == PRC_TM_EDGE && all_classed && ne > 0) { hmode[t] = PRC_TM_SINGLES; class_tiles++; class_edges += ne; }
         }
         PRC_TRY(hipMemcpyAsync(mode.p, hmode.data(), hmode.size(), hipMemcpyHostToDevice, s), "copy");
         if (class_tiles == 0) continue;   // (round 1 only re-derives what it already has: cheap next to the sort)
@@ -1613,7 +1627,7 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
         const int64_t thr2 = (int64_t) ch2 * prc_env_int("GMX_PR_COLD_SPLIT_X100", 300) / 100;
         for (int64_t t = 0; t < c->ntiles; t++) {
             const int64_t v0 = t << PRC_CLS_BITS;
-            if (hmode[t] == PRC_TM_CLASSED) {   // one run of groups over all class streams of the tile (whole blocks; the padding ends no item)
+            if (hmode[t] == PRC_TM_CLASSED || hmode[t] == PRC_TM_SINGLES) {   // one run of groups over all class streams of the tile (whole blocks; the padding ends no item)
                 const int32_t g0 = vstart[v0 + PRC_CL_E1], g1 = vstart[v0 + PRC_CL_H + 1];
                 for (int32_t g = g0; g < g1; g += ch1) v1p.push_back({(int32_t) t, g, std::min(g1, g + ch1), PRC_FORM_TILE});
                 continue;
@@ -1694,9 +1708,8 @@ int64_t pr_cold_edges(const pr_cold* c) { return c ? c->Ec : 0; }
 int64_t pr_cold_items(const pr_cold* c) { return c ? c->P2 : 0; }
 
 // phase 1 over the tile classes [k0, k1): per class the class-form items, then the generic pair / edge items
-template <typename S>
-static void prc_gather(pr_cold* c, const void* contrib, int k0, int k1, hipStream_t s) {
-    constexpr int TILE = prc_tile_elems((int) sizeof(S));
+template <typename S, int TILE>
+static void prc_gather_tile(pr_cold* c, const void* contrib, int k0, int k1, hipStream_t s) {
     const int64_t span = c->prm.slice - c->prm.T;
     for (int k = k0; k < k1; k++) {
         const int64_t nc = c->o1g[k] - c->o1[k], ng = c->o1[k + 1] - c->o1g[k];
@@ -1707,14 +1720,21 @@ static void prc_gather(pr_cold* c, const void* contrib, int k0, int k1, hipStrea
                                c->prm.slice, c->prm.T, (const uint16_t*) c->srcl.p, (const int32_t*) c->ob.p, (S*) c->val.p, (unsigned) c->P2, c->q1c, (const int32_t*) c->vstart.p);
             c->q1c += (uint32_t) nc + grid;   // every workgroup claims until its first miss
         }
-        if (ng > 0) {
-            const unsigned grid = (unsigned) std::min<int64_t>(c->grid, ng);
-            hipLaunchKernelGGL((pr_cold_tile_kernel<S, TILE, false>), dim3(grid), dim3(PRC_THREADS), 0, s,
-                               (const prc_item1*) c->it1p.p + c->o1g[k], (int) ng, c->queue.p, (const S*) contrib, (const int32_t*) c->torg.p, c->prm.nranks, span,
-                               c->prm.slice, c->prm.T, (const uint16_t*) c->srcl.p, (const int32_t*) c->ob.p, (S*) c->val.p, (unsigned) c->P2, c->q1, (const int32_t*) c->vstart.p);
-            c->q1 += (uint32_t) ng + grid;
+        if constexpr (TILE == prc_tile_elems((int) sizeof(S))) {   // (the generic forms exist with their own tile size only)
+            if (ng > 0) {
+                const unsigned grid = (unsigned) std::min<int64_t>(c->grid, ng);
+                hipLaunchKernelGGL((pr_cold_tile_kernel<S, TILE, false>), dim3(grid), dim3(PRC_THREADS), 0, s,
+                                   (const prc_item1*) c->it1p.p + c->o1g[k], (int) ng, c->queue.p, (const S*) contrib, (const int32_t*) c->torg.p, c->prm.nranks, span,
+                                   c->prm.slice, c->prm.T, (const uint16_t*) c->srcl.p, (const int32_t*) c->ob.p, (S*) c->val.p, (unsigned) c->P2, c->q1, (const int32_t*) c->vstart.p);
+                c->q1 += (uint32_t) ng + grid;
+            }
         }
     }
+}
+template <typename S>
+static void prc_gather(pr_cold* c, const void* contrib, int k0, int k1, hipStream_t s) {
+    if (c->tile == prc_tile_elems_classed((int) sizeof(S))) prc_gather_tile<S, prc_tile_elems_classed((int) sizeof(S))>(c, contrib, k0, k1, s);
+    else prc_gather_tile<S, prc_tile_elems((int) sizeof(S))>(c, contrib, k0, k1, s);
 }
 
 // phases 2 and 3 of part q

@@ -540,6 +540,46 @@ def test_pagerank_cold_sources_binned(gmx, scale, nranks, chunks, elem, hot, chu
     g.free()
 
 
+@pytest.mark.parametrize("density", [0, 64, 4096])
+@pytest.mark.parametrize("scale,nranks,elem", [(18, 1, 4), (18, 1, 8), (19, 2, 4), (17, 3, 8)])
+def test_pagerank_binned_forms_agree(gmx, scale, nranks, elem, density, monkeypatch):
+    """The tile-major stream has three storage forms (gmx_pr_cold.hip): length classes for every tile (the default),
+    round 2's generic pair / edge forms (GMX_PR_COLD_CLASS_DENSITY=0), and the mix (classes only where the (tile, bin)
+    cells are dense enough).  Each must match the oracle; the plans differ in tile size and item order, so the fp32 ranks
+    may differ between them in the last bits, the fp64 ones agree to 1e-12."""
+    import torch
+    monkeypatch.setenv("GMX_PR_COLD", "0")
+    monkeypatch.setenv("GMX_PR_COLD_CLASS_DENSITY", str(density))
+    og = po.rmat_graph(scale, permute=True)
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    iters = 5
+    want, _, _ = po.pagerank(og, 1e-300, 0.85, iters)
+    options = gmx.GMX_PR_RELABEL | gmx.GMX_PR_HOT_LDS | gmx.GMX_PR_SLICED | gmx.GMX_PR_COLD_PB
+    states = [gmx.PageRankState(g, elem, r, nranks, options) for r in range(nranks)]
+    need = states[0].exchange_count()
+    n = torch.as_tensor(states[0].contrib_slice(), device="cuda").numel()
+    for s_ in states:
+        s_.reset(0.85)
+
+    def exchange(fulls):
+        for dst in fulls:
+            for r, src in enumerate(fulls):
+                if dst is not src:
+                    dst[r * n:r * n + need].copy_(src[r * n:r * n + need])
+        torch.cuda.synchronize()
+    exchange([torch.as_tensor(s_.contrib_full(), device="cuda") for s_ in states])
+    for _ in range(iters):
+        for s_ in states:
+            s_.step()
+        exchange([torch.as_tensor(s_.contrib_full(), device="cuda") for s_ in states])
+    out = np.zeros(og.N, dtype=np.float64 if elem == 8 else np.float32)
+    for s_ in states:
+        s_.download(out)
+        s_.free()
+    g.free()
+    assert rel_err(out, want) < (PR_RTOL_F64 if elem == 8 else PR_RTOL_F32)
+
+
 @pytest.mark.parametrize("scale,nranks,elem", [(18, 4, 4), (17, 2, 8), (19, 8, 4), (16, 3, 8), (22, 2, 4)])
 def test_pagerank_pipelined_gather_order(gmx, scale, nranks, elem, monkeypatch):
     """The pipelined form of the pushed step (gmx_pr_step_gather): phase 1 over the class-0 tiles may run while the

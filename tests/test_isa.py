@@ -21,7 +21,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reaso
 def test_tile_kernel_waits_are_sufficient_and_nothing_spills():
     import isa_check
     res = isa_check.check_file(SRC)
-    assert len(res) == 4, list(res)                       # fp32 and fp64, class forms and generic forms
+    assert len(res) == 6, list(res)                       # fp32 and fp64: class forms (two tile sizes) and generic forms
     for name, (errors, stats) in res.items():
         assert not errors, (name, errors[:5])
         assert stats["scratch"] == 0 and 0 < stats["vgprs"] <= 128, stats
