@@ -97,21 +97,31 @@ extern "C" int gmx_copy_bandwidth(int64_t bytes, int iters, double* gbs) {
 
 // ------------------------------------------------------------------ keys <-> CSR
 // key = (row << 32 | col); 2^31 vertices max (node_t is int32).
+#define KFC_CHUNK 16   // consecutive edges per thread: one binary search for the row of the first, then a walk along begin[]
 __global__ void keys_from_csr_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ idx,
                                      int64_t V, int64_t E, int transpose, const int32_t* __restrict__ perm,
                                      uint64_t* __restrict__ keys) {
-    // one thread per edge; the row of an edge is found by binary search on begin[]
-    int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t stride = (int64_t) gridDim.x * blockDim.x;
-    for (; e < E; e += stride) {
-        int64_t lo = 0, hi = V;  // largest r with begin[r] <= e
+    int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x, nchunks = (E + KFC_CHUNK - 1) / KFC_CHUNK;
+    for (; c < nchunks; c += stride) {
+        const int64_t e0 = c * KFC_CHUNK, e1 = e0 + KFC_CHUNK < E ? e0 + KFC_CHUNK : E;
+        int64_t lo = 0, hi = V;  // largest r with begin[r] <= e0
         while (hi - lo > 1) {
             int64_t mid = (lo + hi) >> 1;
-            if ((int64_t) begin[mid] <= e) lo = mid; else hi = mid;
+            if ((int64_t) begin[mid] <= e0) lo = mid; else hi = mid;
         }
-        uint32_t r = (uint32_t) lo, c = (uint32_t) idx[e];
-        if (perm) { r = (uint32_t) perm[r]; c = (uint32_t) perm[c]; }
-        keys[e] = transpose ? (((uint64_t) c << 32) | r) : (((uint64_t) r << 32) | c);
+        int64_t row = lo, next = begin[row + 1];
+        uint32_t r = perm ? (uint32_t) perm[row] : (uint32_t) row;
+        for (int64_t e = e0; e < e1; e++) {
+            while (e >= next) {   // (rows without edges are skipped)
+                row++;
+                next = begin[row + 1];
+                r = perm ? (uint32_t) perm[row] : (uint32_t) row;
+            }
+            uint32_t col = (uint32_t) idx[e];
+            if (perm) col = (uint32_t) perm[col];
+            keys[e] = transpose ? (((uint64_t) col << 32) | r) : (((uint64_t) r << 32) | col);
+        }
     }
 }
 
@@ -154,7 +164,7 @@ static int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
 int gmx_keys_from_csr(const int32_t* begin, const int32_t* idx, int64_t V, int64_t E,
                       bool transpose, const int32_t* perm, uint64_t* keys, hipStream_t stream) {
     if (E == 0) return GMX_OK;
-    hipLaunchKernelGGL(keys_from_csr_kernel, dim3(grid_for(E)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(keys_from_csr_kernel, dim3(grid_for((E + KFC_CHUNK - 1) / KFC_CHUNK)), dim3(256), 0, stream,
                        begin, idx, V, E, transpose ? 1 : 0, perm, keys);
     GMX_HIP(hipGetLastError());
     return GMX_OK;

@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <string.h>
+#include <time.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -158,6 +160,22 @@ int gmx_pr_multi_create(gmx_graph* g, int elem, int nranks, gmx_pr_multi** out);
 int gmx_pr_multi_run(gmx_pr_multi* m, double e, double d, int32_t max_iter, void* rank_host, gmx_stats_t* stats);
 void gmx_pr_multi_free(gmx_pr_multi* m);
 bool gmx_pr_multi_verified(const gmx_pr_multi* m);   // false: the first exchange has not passed its check
+
+// GMX_PLAN_TIMING=1: where a plan build spends its time (synchronises at every mark)
+struct gmx_tick {
+    bool on;
+    double t0;
+    const char* who;
+    static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+    explicit gmx_tick(const char* w) : on(getenv("GMX_PLAN_TIMING") != nullptr), t0(0), who(w) { if (on) { (void) hipDeviceSynchronize(); t0 = now(); } }
+    void mark(const char* what) {
+        if (!on) return;
+        (void) hipDeviceSynchronize();
+        const double t = now();
+        fprintf(stderr, "gmx timing %s: %-28s %8.2f ms\n", who, what, (t - t0) * 1e3);
+        t0 = t;
+    }
+};
 
 static inline int gmx_bits_for(int64_t v) {  // bits needed to represent values in [0, v)
     int b = 1;

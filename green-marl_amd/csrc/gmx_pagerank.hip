@@ -332,6 +332,12 @@ __global__ void pr_blocks_kernel(const int32_t* __restrict__ rb, int64_t rows, i
     blk[k].e = (int32_t) (dk - lo);
 }
 
+// selects the in-edges of the owned rows out of (row << 32 | source) keys
+struct pr_row_in_range {
+    uint64_t lo, hi;
+    __device__ bool operator()(const uint64_t& k) const { return k >= lo && k < hi; }
+};
+
 // selects the in-edges the pull sweep keeps: source inside the hot prefix of its rank range
 struct pr_is_hot_key {
     uint32_t slice, T;
@@ -1181,6 +1187,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
     const int64_t V = g->V, E = g->E;
     hipStream_t s = 0;
     int st = GMX_OK;
+    gmx_tick tick("pr plan");
     do {
         if ((st = p->inv.alloc((size_t) p->rows)) || (st = p->outdeg.alloc((size_t) p->rows))) break;
         if (p->rows && (hipMemset(p->inv.p, 0xff, sizeof(int32_t) * (size_t) p->rows) != hipSuccess ||
@@ -1234,7 +1241,35 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
             if ((st = keys.alloc((size_t) E)) || (st = alt.alloc((size_t) E))) break;
             if ((st = gmx_keys_from_csr(g->r_begin.p, g->r_node_idx.p, V, E, false, perm.p, keys.p, s))) break;
             const uint64_t* sorted = keys.p;
-            if (E > 1) {
+            tick.mark("degree order, keys");
+            // Every in-edge binned (the default from 2^20 vertices): the binned plan orders its edges itself and asks for
+            // them in ANY order, so the (row, source) sort of all E keys -- the most expensive step of a plan build -- is
+            // left out: with one rank the keys are used as they come, with several the owned rows are selected (stable).
+            int64_t cold_T_req = 0;
+            {
+                const char* ev = getenv("GMX_PR_COLD");
+                if (ev && *ev) cold_T_req = atoll(ev);
+                if (p->ns > 0) cold_T_req = cold_T_req / ((int64_t) p->ns << PR_RUN_SHIFT) * ((int64_t) p->ns << PR_RUN_SHIFT);
+            }
+            const bool unsorted_ok = p->ns > 0 && (options & GMX_PR_COLD_PB) && cold_T_req == 0 && ((int64_t) p->ns << PR_RUN_SHIFT) <= p->slice;
+            int64_t hb[2] = {0, 0};
+            if (unsorted_ok) {
+                if (nranks == 1) hb[1] = E;
+                else {
+                    dbuf<int64_t> nsel;
+                    if ((st = nsel.alloc(1))) break;
+                    pr_row_in_range pred{(uint64_t) p->row_lo << 32, (uint64_t) (p->row_lo + p->rows) << 32};
+                    size_t tb = 0;
+                    hipError_t he = rocprim::select(nullptr, tb, (const uint64_t*) keys.p, alt.p, nsel.p, (size_t) E, pred, s);
+                    dbuf<char> tmp;
+                    if (he == hipSuccess && (st = tmp.alloc(tb))) break;
+                    if (he == hipSuccess) he = rocprim::select((void*) tmp.p, tb, (const uint64_t*) keys.p, alt.p, nsel.p, (size_t) E, pred, s);
+                    if (he == hipSuccess) he = hipMemcpy(&hb[1], nsel.p, sizeof(int64_t), hipMemcpyDeviceToHost);
+                    if (he != hipSuccess) { gmx_set_error("pr plan: owned-row selection failed: %s", hipGetErrorString(he)); st = GMX_ERR_HIP; break; }
+                    sorted = alt.p;
+                }
+            }
+            if (!unsorted_ok && E > 1) {
                 rocprim::double_buffer<uint64_t> db(keys.p, alt.p);
                 size_t tb = 0;
                 unsigned end_bit = 32 + (unsigned) gmx_bits_for(p->Vpad);
@@ -1246,12 +1281,13 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 if (he != hipSuccess) { gmx_set_error("pr plan: key sort failed: %s", hipGetErrorString(he)); st = GMX_ERR_HIP; break; }
                 sorted = db.current();
             }
-            dbuf<int64_t> bounds;
-            if ((st = bounds.alloc(2))) break;
-            hipLaunchKernelGGL(pr_key_bound_kernel, dim3(1), dim3(64), 0, s, sorted, E,
-                               (uint64_t) p->row_lo << 32, (uint64_t) (p->row_lo + p->rows) << 32, bounds.p);
-            int64_t hb[2] = {0, 0};
-            if (hipMemcpy(hb, bounds.p, sizeof(hb), hipMemcpyDeviceToHost) != hipSuccess) { gmx_set_error("pr plan: bounds copy failed"); st = GMX_ERR_HIP; break; }
+            if (!unsorted_ok) {
+                dbuf<int64_t> bounds;
+                if ((st = bounds.alloc(2))) break;
+                hipLaunchKernelGGL(pr_key_bound_kernel, dim3(1), dim3(64), 0, s, sorted, E,
+                                   (uint64_t) p->row_lo << 32, (uint64_t) (p->row_lo + p->rows) << 32, bounds.p);
+                if (hipMemcpy(hb, bounds.p, sizeof(hb), hipMemcpyDeviceToHost) != hipSuccess) { gmx_set_error("pr plan: bounds copy failed"); st = GMX_ERR_HIP; break; }
+            }
             p->El = hb[1] - hb[0];
             p->Eh = p->El;
             if (p->ns > 0) {
@@ -1276,7 +1312,11 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                     const int64_t margin = unit;
                     if (T >= 0 && T + margin <= p->slice && p->El > 0) p->cold_T = T;
                 }
-                if (p->cold_T >= 0) {
+                if (p->cold_T >= 0 && unsorted_ok) {   // nothing stays with the pull sweep
+                    p->Eh = 0;
+                    cold_keys = own;
+                    Ec = p->El;
+                } else if (p->cold_T >= 0) {
                     uint64_t* other = (sorted == keys.p) ? alt.p : keys.p;
                     dbuf<int64_t> nsel;
                     if ((st = nsel.alloc(1))) break;
@@ -1379,6 +1419,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                     }
                     if (hipStreamSynchronize(s) != hipSuccess) { gmx_set_error("pr plan: active-row renaming failed"); st = GMX_ERR_HIP; break; }
                 }
+                tick.mark("owned rows, active rows");
                 if (p->cold_T >= 0) {   // tile- and bin-major streams of the binned edges
                     dbuf<int32_t> deg_by_id;
                     if ((st = deg_by_id.alloc((size_t) p->Vpad))) break;
@@ -1455,6 +1496,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { gmx_set_error("hipGetDeviceProperties failed"); st = GMX_ERR_HIP; break; }
         p->persistent_grid = prop.multiProcessorCount;
         if (p->ns > 0 && (st = pr_build_chunks(p, 1))) break;
+        tick.mark("binned plan + rest");
     } while (0);
     if (st != GMX_OK) { delete p; return st; }
     *out = p;

@@ -456,11 +456,22 @@ __global__ void prc_tile_maxdeg_kernel(const int32_t* __restrict__ deg, int64_t 
     int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
     const int64_t span = slice - T;
-    for (; i < nids; i += stride) {
-        const int64_t l = i % slice;
-        const int32_t dg = deg[i];
-        if (l < T || dg <= 0) continue;
-        atomicMax(&tmax[((i / slice) * span + (l - T)) / tile_src], dg);
+    for (int64_t base = i - (threadIdx.x & 63); base < nids; base += stride) {   // (whole waves: the shuffles below need them)
+        const int64_t id = base + (threadIdx.x & 63);
+        int32_t dg = 0;
+        int64_t t = -1;
+        if (id < nids) {
+            const int64_t l = id % slice;
+            dg = deg[id];
+            if (l >= T && dg > 0) t = ((id / slice) * span + (l - T)) / tile_src;
+        }
+        // 64 consecutive ids lie in one tile or two: the lanes that share the first lane's tile reduce among themselves
+        const int64_t t0 = __shfl(t, 0, 64);
+        int32_t m = t == t0 ? dg : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+        if ((threadIdx.x & 63) == 0 && t0 >= 0 && m > 0) atomicMax(&tmax[t0], m);
+        if (t >= 0 && t != t0) atomicMax(&tmax[t], dg);
     }
 }
 
@@ -1368,6 +1379,7 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
     // (measured on RMAT-26 fp32 with the generic form's tile, ms per step: density 0 -> 1.75, 1024 (80 tiles classed) -> 1.49,
     // 256 (189 tiles) -> 1.46, every pair tile -> 1.43: the (class, bin) sub-cells stay fuller than feared, 1.51 M -> 1.61 M cells)
     int st = GMX_OK;
+    gmx_tick tick("cold plan");
     dbuf<uint64_t> k1, k2;
     dbuf<int32_t> cflag, cincl, ps, pincl, pstart, plen, ppos, pos, endf, endpre, first, pfirst, groups, c1raw, c1, vtab, delta, counts, id, order2, groups2,
         c2s, c2, tab2, tstat;
@@ -1407,12 +1419,15 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
         rocprim::double_buffer<uint64_t> db(k1.p, k2.p);
         size_t tb = 0;
         const unsigned end_bit = 32u + (unsigned) binbits + (unsigned) vtbits;
-        PRC_TRY(rocprim::radix_sort_keys(nullptr, tb, db, (size_t) Ec, 0u, end_bit, s), "sort size");
+        // (the 16 source bits stay out of the sort: the sort is stable, so a pair's sources keep the order the caller's
+        // keys came in -- a fixed order is all the sums need -- and two of eight radix passes are saved)
+        PRC_TRY(rocprim::radix_sort_keys(nullptr, tb, db, (size_t) Ec, 16u, end_bit, s), "sort size");
         PRC_ALLOC(tmp, tb);
-        PRC_TRY(rocprim::radix_sort_keys((void*) tmp.p, tb, db, (size_t) Ec, 0u, end_bit, s), "sort");
+        PRC_TRY(rocprim::radix_sort_keys((void*) tmp.p, tb, db, (size_t) Ec, 16u, end_bit, s), "sort");
         PRC_TRY(hipStreamSynchronize(s), "sort sync");
         sk = db.current();
     }
+    tick.mark("keys + main sort");
     PRC_ALLOC(cflag, Ec + 1);
     PRC_ALLOC(cincl, Ec + 1);
     PRC_ALLOC(ps, Ec + 1);
@@ -1469,6 +1484,7 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
         }
     }
     if (sk == k1.p) k2.release(); else k1.release();
+    tick.mark("runs, classes, class sort");
     ps.release();
     // ---- padded pair lengths -> stream offsets; cells; groups per cell ----
     PRC_ALLOC(plen, np + 1);
@@ -1493,6 +1509,7 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
     PRC_TRY(hipMemcpyAsync(hvt.data(), vtab.p, sizeof(int32_t) * hvt.size(), hipMemcpyDeviceToHost, s), "copy");
     PRC_TRY(hipStreamSynchronize(s), "sync");
     cflag.release();
+    tick.mark("pair lengths, cells, groups");
     // ---- where the streams of the virtual tiles start: the generic pair form runs whole super-steps, every other
     //      stream starts on a block boundary ----
     hdelta.assign((size_t) nvt + 1, 0);
@@ -1523,6 +1540,7 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
                        (const int32_t*) pincl.p, (const int32_t*) pstart.p, (const int32_t*) ppos.p, (const int32_t*) pfirst.p,
                        (const int32_t*) c1.p, (const uint8_t*) mode.p, binbits, prm.elem, Ec, pos.p, endf.p);
     PRC_TRY(prc_exscan(endf.p, endpre.p, Ec + 1, tmp, s), "scan");   // endpre: item ends before an edge
+    tick.mark("positions, item ends");
     pincl.release();
     PRC_ALLOC(counts, nc + 1);
     PRC_ALLOC(key2, nc);
@@ -1562,6 +1580,7 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
         goto done;
     }
     c->P2 = ngroups2 * PRC_G;
+    tick.mark("bin-major order");
     // ---- the two streams ----
     PRC_ALLOC(c->srcl, c->P1);
     PRC_ALLOC(c->ob, ngroups1);
@@ -1582,6 +1601,7 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
     h2.resize((size_t) c->nbins + 1);
     PRC_TRY(hipMemcpyAsync(h2.data(), tab2.p, sizeof(int32_t) * h2.size(), hipMemcpyDeviceToHost, s), "copy");
     PRC_TRY(hipStreamSynchronize(s), "sync");
+    tick.mark("streams filled");
     {   // an accumulator never receives more terms than its bin has items: that bound sizes the second limb
         int64_t biggest = 1;
         for (int64_t b = 0; b < c->nbins; b++) biggest = std::max<int64_t>(biggest, ((int64_t) h2[b + 1] - h2[b]) * PRC_G);
@@ -1621,7 +1641,7 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
         // and read again: a bin is cut when it exceeds three chunks).
         const int64_t want1 = std::max<int64_t>(ngroups1 / ((int64_t) c->grid * 4), std::min<int64_t>(8192, ngroups1 / ((int64_t) c->grid * 2)));
         const int64_t want2 = ngroups2 / ((int64_t) c->grid * 2);
-        const int ch1 = (int) std::min<int64_t>(32768, std::max<int64_t>(PRC_SUPER_GROUPS, prc_env_int("GMX_PR_COLD_CHUNK1", (int) std::min<int64_t>(want1, 32768)))) / PRC_SUPER_GROUPS * PRC_SUPER_GROUPS;
+        const int ch1 = (int) std::min<int64_t>(262144, std::max<int64_t>(PRC_SUPER_GROUPS, prc_env_int("GMX_PR_COLD_CHUNK1", (int) std::min<int64_t>(want1, 32768)))) / PRC_SUPER_GROUPS * PRC_SUPER_GROUPS;
         const int ch2 = (int) std::min<int64_t>(32768, std::max<int64_t>(8, prc_env_int("GMX_PR_COLD_CHUNK", (int) std::min<int64_t>(std::max<int64_t>(want2, 2048), 32768)))) / 8 * 8;
         // a bin is split when it exceeds thr2 (a split costs its accumulators written and read again)
         const int64_t thr2 = (int64_t) ch2 * prc_env_int("GMX_PR_COLD_SPLIT_X100", 300) / 100;
@@ -1670,6 +1690,7 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
         if ((st = prc_upload_lists(c, nullptr, nullptr, 1))) goto done;
     }
     PRC_TRY(hipStreamSynchronize(s), "sync");
+    tick.mark("tables, work lists");
     if (getenv("GMX_PR_DEBUG")) {
         std::vector<int64_t> bs;
         for (int64_t b = 0; b < c->nbins; b++) bs.push_back(((int64_t) h2[b + 1] - h2[b]) * PRC_G);
