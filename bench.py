@@ -311,6 +311,8 @@ def main():
                                     if pr.exchange == "push" else "RCCL all-gather of contribution slices, %d row chunk(s)") % chunks
                                    + ("; pipelined: the tail chunk travels under the next step's gather over the hub tiles" if pipelined else ""),
                        "exchange_check": exchange_check,
+                       "exchange_bytes_per_rank_and_step": (engine.exchange_bytes() if world > 1 else 0),
+                       "exchange_packed": bool(world > 1 and engine.packed()),
                        "step_form": "single rank" if world == 1 and not force_coll else
                                     (("pushed, pipelined" if pipelined else "pushed, plain") if pr.exchange == "push" else "collective")
                                     + (" (fell back from the pipelined form)" if fell_back else ""),

@@ -129,6 +129,19 @@ struct gmx_pr {
     // first by the peers' next step) does not queue behind the long tail piece
     std::vector<hipStream_t> push_stream[2]; // [nranks]
     std::vector<hipEvent_t> push_done[2];    // [nranks]
+    // packed exchange ("send only what is read", nranks > 1 with the degree order): rank q reads source w iff w has an
+    // out-edge into a row q owns.  send_list[q]: positions in MY range that rank q reads (ascending); recv_list[r]: positions
+    // in rank r's range that I read -- the same list rank r holds as its send_list[me], by construction of both from the
+    // same edges.  A pushed chunk is packed per peer into sbuf, copied into the peer's landing zone rbuf[parity] at the
+    // offset of my segment there, and scattered into the peer's replica by gmx_pr_unpack.
+    bool packed = false;
+    std::vector<int64_t> send_cnt, send_off, recv_cnt, recv_off;   // [nranks] elements; offsets into slist / sbuf and rlist / rbuf
+    dbuf<int32_t> slist, rlist;              // concatenated send / recv position lists
+    dbuf<char> sbuf, rbuf[2];                // packed staging (send) and landing zones (recv, by replica parity)
+    std::vector<char*> peer_rbuf[2];         // [nranks] base of rank r's rbuf[b]
+    std::vector<int64_t> peer_roff;          // [nranks] where MY segment starts in rank r's landing zone (elements)
+    std::vector<int64_t> sbound, rbound;     // [nranks * (nchunks + 1)] chunk boundaries inside the per-peer lists (list indices)
+    int bound_chunks = 0;                    // the chunk count sbound / rbound were made for
     int gather_mask = 0;                     // tile classes whose phase 1 has been enqueued for the running step (binned, fused form)
     hipEvent_t push_ready = nullptr;         // "this chunk is computed", recorded on the step's stream
     double* h_diff = nullptr;                // pinned landing place of gmx_pr_diff
@@ -330,6 +343,86 @@ __global__ void pr_blocks_kernel(const int32_t* __restrict__ rb, int64_t rows, i
     }
     blk[k].r = (int32_t) lo;
     blk[k].e = (int32_t) (dk - lo);
+}
+
+// ---- packed exchange lists ----
+// rmask[l] bit q: owned source l (position in this rank's range) has an out-edge into a row of rank q.  One thread per
+// KFC-sized run of forward edges; a bit already set is not written again (hubs would otherwise serialise on one word).
+__global__ void pr_reader_mask_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ idx, int64_t V, int64_t E,
+                                      const int32_t* __restrict__ perm, int64_t slice, int64_t row_lo, int64_t rows, unsigned int* __restrict__ rmask) {
+    constexpr int CH = 16;
+    int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x, nchunks = (E + CH - 1) / CH;
+    for (; c < nchunks; c += stride) {
+        const int64_t e0 = c * CH, e1 = e0 + CH < E ? e0 + CH : E;
+        int64_t lo = 0, hi = V;
+        while (hi - lo > 1) {
+            int64_t mid = (lo + hi) >> 1;
+            if ((int64_t) begin[mid] <= e0) lo = mid; else hi = mid;
+        }
+        int64_t row = lo, next = begin[row + 1];
+        int64_t l = (int64_t) perm[row] - row_lo;
+        unsigned int have = 0, known = 0;
+        for (int64_t e = e0; e < e1; e++) {
+            while (e >= next) {
+                row++;
+                next = begin[row + 1];
+                l = (int64_t) perm[row] - row_lo;
+                known = 0;
+            }
+            if (l < 0 || l >= rows) continue;
+            if (!known) { have = rmask[l]; known = 1; }
+            const unsigned int bit = 1u << (unsigned) (perm[idx[e]] / slice);
+            if (!(have & bit)) { atomicOr(&rmask[l], bit); have |= bit; }
+        }
+    }
+}
+// mark[src] = 1 for every source among the keys (row << 32 | source)
+__global__ void pr_mark_sources_kernel(const uint64_t* __restrict__ keys, int64_t n, uint8_t* __restrict__ mark) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) mark[(uint32_t) keys[i]] = 1;
+}
+struct pr_mask_has_bit {
+    const unsigned int* rmask;
+    unsigned int bit;
+    __device__ bool operator()(const int32_t& l) const { return (rmask[l] & bit) != 0; }
+};
+struct pr_is_marked {
+    const uint8_t* mark;   // already offset to the range
+    __device__ bool operator()(const int32_t& l) const { return mark[l] != 0; }
+};
+// first index of a sorted int32 list holding a value >= t, for a few (list, t) pairs: q[3 i] = list offset, q[3 i + 1] = length, q[3 i + 2] = t
+__global__ void pr_list_bounds_kernel(const int32_t* __restrict__ list, const int64_t* __restrict__ q, int nq, int64_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const int32_t* a = list + q[3 * i];
+    int64_t lo = 0, hi = q[3 * i + 1];
+    const int64_t t = q[3 * i + 2];
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t) a[mid] < t) lo = mid + 1; else hi = mid;
+    }
+    out[i] = lo;
+}
+// sbuf[off[q] + i] = own[list[off[q] + i]] for i in [lo[q], hi[q]) of every peer q (blockIdx.y)
+struct pr_pack_args { int64_t off[16], lo[16], hi[16]; };
+template <typename S>
+__global__ void pr_pack_kernel(pr_pack_args a, const int32_t* __restrict__ list, const S* __restrict__ own, S* __restrict__ out) {
+    const int q = blockIdx.y;
+    const int64_t n = a.hi[q] - a.lo[q], base = a.off[q] + a.lo[q];
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[base + i] = own[list[base + i]];
+}
+// replica[r * slice + list[off[r] + i]] = in[off[r] + i] for i in [lo[r], hi[r]) of every sender r (blockIdx.y)
+template <typename S>
+__global__ void pr_unpack_kernel(pr_pack_args a, const int32_t* __restrict__ list, const S* __restrict__ in, S* __restrict__ replica, int64_t slice) {
+    const int r = blockIdx.y;
+    const int64_t n = a.hi[r] - a.lo[r], base = a.off[r] + a.lo[r];
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) replica[(int64_t) r * slice + list[base + i]] = in[base + i];
 }
 
 // selects the in-edges of the owned rows out of (row << 32 | source) keys
@@ -1419,6 +1512,58 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                     }
                     if (hipStreamSynchronize(s) != hipSuccess) { gmx_set_error("pr plan: active-row renaming failed"); st = GMX_ERR_HIP; break; }
                 }
+                if (nranks > 1 && relabel && nranks <= 16 && !getenv("GMX_PR_NO_PACKED")) {
+                    // ---- packed exchange lists (see the struct) ----
+                    dbuf<unsigned int> rmask;
+                    dbuf<uint8_t> mark;
+                    dbuf<int64_t> nsel;
+                    dbuf<char> tmp;
+                    if ((st = rmask.alloc((size_t) rows)) || (st = mark.alloc((size_t) p->Vpad)) || (st = nsel.alloc(1))) break;
+                    hipError_t he = hipMemsetAsync(rmask.p, 0, sizeof(unsigned int) * (size_t) rows, s);
+                    if (he == hipSuccess) he = hipMemsetAsync(mark.p, 0, (size_t) p->Vpad, s);
+                    if (he != hipSuccess) { gmx_set_error("pr plan: memset failed"); st = GMX_ERR_HIP; break; }
+                    hipLaunchKernelGGL(pr_reader_mask_kernel, dim3(grid_for((E + 15) / 16)), dim3(256), 0, s, g->begin.p, g->node_idx.p, V, E,
+                                       (const int32_t*) perm.p, p->slice, p->row_lo, rows, rmask.p);
+                    if (p->El > 0) hipLaunchKernelGGL(pr_mark_sources_kernel, dim3(grid_for(p->El)), dim3(256), 0, s, own, p->El, mark.p);
+                    dbuf<int32_t> sl_tmp, rl_tmp;
+                    if ((st = sl_tmp.alloc((size_t) p->exchange_count * nranks + 1)) || (st = rl_tmp.alloc((size_t) p->exchange_count * nranks + 1))) break;
+                    p->send_cnt.assign((size_t) nranks, 0); p->send_off.assign((size_t) nranks + 1, 0);
+                    p->recv_cnt.assign((size_t) nranks, 0); p->recv_off.assign((size_t) nranks + 1, 0);
+                    rocprim::counting_iterator<int32_t> ids(0);
+                    bool ok = true;
+                    for (int q = 0; q < nranks && ok; q++) {
+                        for (int dir = 0; dir < 2 && ok; dir++) {   // 0: what rank q reads of mine, 1: what I read of rank q's
+                            int64_t n = 0;
+                            if (q != rank) {
+                                int32_t* out = (dir ? rl_tmp.p + p->recv_off[(size_t) q] : sl_tmp.p + p->send_off[(size_t) q]);
+                                size_t tb = 0;
+                                if (dir == 0) {
+                                    pr_mask_has_bit pred{rmask.p, 1u << q};
+                                    he = rocprim::select(nullptr, tb, ids, out, nsel.p, (size_t) p->exchange_count, pred, s);
+                                    if (he == hipSuccess && tmp.n < tb) { tmp.release(); if (tmp.alloc(tb)) he = hipErrorOutOfMemory; }
+                                    if (he == hipSuccess) he = rocprim::select((void*) tmp.p, tb, ids, out, nsel.p, (size_t) p->exchange_count, pred, s);
+                                } else {
+                                    pr_is_marked pred{mark.p + (size_t) q * (size_t) p->slice};
+                                    he = rocprim::select(nullptr, tb, ids, out, nsel.p, (size_t) p->exchange_count, pred, s);
+                                    if (he == hipSuccess && tmp.n < tb) { tmp.release(); if (tmp.alloc(tb)) he = hipErrorOutOfMemory; }
+                                    if (he == hipSuccess) he = rocprim::select((void*) tmp.p, tb, ids, out, nsel.p, (size_t) p->exchange_count, pred, s);
+                                }
+                                if (he == hipSuccess) he = hipMemcpy(&n, nsel.p, sizeof(int64_t), hipMemcpyDeviceToHost);
+                                if (he != hipSuccess) ok = false;
+                            }
+                            if (dir) { p->recv_cnt[(size_t) q] = n; p->recv_off[(size_t) q + 1] = p->recv_off[(size_t) q] + n; }
+                            else { p->send_cnt[(size_t) q] = n; p->send_off[(size_t) q + 1] = p->send_off[(size_t) q] + n; }
+                        }
+                    }
+                    if (!ok) { gmx_set_error("pr plan: exchange lists failed: %s", hipGetErrorString(he)); st = GMX_ERR_HIP; break; }
+                    const size_t ns_ = (size_t) p->send_off[(size_t) nranks], nr_ = (size_t) p->recv_off[(size_t) nranks];
+                    if ((st = p->slist.alloc(ns_ ? ns_ : 1)) || (st = p->rlist.alloc(nr_ ? nr_ : 1)) || (st = p->sbuf.alloc((ns_ ? ns_ : 1) * elem_bytes)) ||
+                        (st = p->rbuf[0].alloc((nr_ ? nr_ : 1) * elem_bytes)) || (st = p->rbuf[1].alloc((nr_ ? nr_ : 1) * elem_bytes))) break;
+                    if ((ns_ && hipMemcpyAsync(p->slist.p, sl_tmp.p, sizeof(int32_t) * ns_, hipMemcpyDeviceToDevice, s) != hipSuccess) ||
+                        (nr_ && hipMemcpyAsync(p->rlist.p, rl_tmp.p, sizeof(int32_t) * nr_, hipMemcpyDeviceToDevice, s) != hipSuccess) ||
+                        hipStreamSynchronize(s) != hipSuccess) { gmx_set_error("pr plan: exchange list copy failed"); st = GMX_ERR_HIP; break; }
+                    p->packed = true;
+                }
                 tick.mark("owned rows, active rows");
                 if (p->cold_T >= 0) {   // tile- and bin-major streams of the binned edges
                     dbuf<int32_t> deg_by_id;
@@ -1877,22 +2022,12 @@ extern "C" int gmx_pr_contrib_buffers(gmx_pr_t* p, void** buf0, void** buf1, int
     return GMX_OK;
 }
 
+static int pr_ensure_push_streams(gmx_pr* p);
 extern "C" int gmx_pr_set_peers(gmx_pr_t* p, void* const* peer_buf0, void* const* peer_buf1) {
     GMX_REQUIRE(p && peer_buf0 && peer_buf1, "NULL argument");
     for (int r = 0; r < p->nranks; r++)
         if (r != p->rank) GMX_REQUIRE(peer_buf0[r] && peer_buf1[r], "peer %d: NULL replica pointer", r);
-    if (p->push_stream[0].empty()) {
-        for (int q = 0; q < 2; q++) {
-            p->push_stream[q].assign((size_t) p->nranks, nullptr);
-            p->push_done[q].assign((size_t) p->nranks, nullptr);
-            for (int r = 0; r < p->nranks; r++) {
-                if (r == p->rank) continue;
-                GMX_HIP(hipStreamCreateWithFlags(&p->push_stream[q][r], hipStreamNonBlocking));
-                GMX_HIP(hipEventCreateWithFlags(&p->push_done[q][r], hipEventDisableTiming));
-            }
-        }
-        GMX_HIP(hipEventCreateWithFlags(&p->push_ready, hipEventDisableTiming));
-    }
+    GMX_CHECK(pr_ensure_push_streams(p));
     p->peer_buf[0].assign((char* const*) peer_buf0, (char* const*) peer_buf0 + p->nranks);
     p->peer_buf[1].assign((char* const*) peer_buf1, (char* const*) peer_buf1 + p->nranks);
     return GMX_OK;
@@ -1946,6 +2081,175 @@ extern "C" int gmx_pr_push_join_chunk(gmx_pr_t* p, int chunk, void* stream) {
     GMX_REQUIRE(p, "pr is NULL");
     GMX_REQUIRE(chunk >= 0 && chunk < p->nchunks, "chunk %d out of range", chunk);
     return pr_push_join_set(p, chunk & 1, (hipStream_t) stream);
+}
+
+// ------------------------------------------------------------------ packed exchange
+// "Send only what is read": see the members of gmx_pr.  The host side wires the ranks up like the plain push
+// (gmx_pr_recv_buffers -> gmx_ipc_export -> transport -> gmx_ipc_open -> gmx_pr_set_peers_packed, plus the offsets each
+// rank reports through gmx_pr_packed_info), then per chunk gmx_pr_push_packed after gmx_pr_step_chunk, the per-step
+// barrier, and gmx_pr_unpack before the next step's phase 1 reads the replica.
+extern "C" int gmx_pr_packed_info(gmx_pr_t* p, int64_t* send_counts, int64_t* recv_counts, int64_t* recv_offsets) {
+    GMX_REQUIRE(p, "pr is NULL");
+    if (!p->packed) return GMX_ERR_STATE;   // (not an error to report: the plan has no lists -- one rank, or not the degree order)
+    for (int r = 0; r < p->nranks; r++) {
+        if (send_counts) send_counts[r] = p->send_cnt[(size_t) r];
+        if (recv_counts) recv_counts[r] = p->recv_cnt[(size_t) r];
+        if (recv_offsets) recv_offsets[r] = p->recv_off[(size_t) r];
+    }
+    return GMX_OK;
+}
+
+extern "C" int gmx_pr_recv_buffers(gmx_pr_t* p, void** buf0, void** buf1, int64_t* bytes) {
+    GMX_REQUIRE(p && buf0 && buf1 && bytes, "NULL argument");
+    GMX_REQUIRE(p->packed, "the plan has no packed exchange lists");
+    *buf0 = p->rbuf[0].p;
+    *buf1 = p->rbuf[1].p;
+    *bytes = (int64_t) p->rbuf[0].n;
+    return GMX_OK;
+}
+
+static int pr_ensure_push_streams(gmx_pr* p) {
+    if (!p->push_stream[0].empty()) return GMX_OK;
+    for (int q = 0; q < 2; q++) {
+        p->push_stream[q].assign((size_t) p->nranks, nullptr);
+        p->push_done[q].assign((size_t) p->nranks, nullptr);
+        for (int r = 0; r < p->nranks; r++) {
+            if (r == p->rank) continue;
+            GMX_HIP(hipStreamCreateWithFlags(&p->push_stream[q][r], hipStreamNonBlocking));
+            GMX_HIP(hipEventCreateWithFlags(&p->push_done[q][r], hipEventDisableTiming));
+        }
+    }
+    GMX_HIP(hipEventCreateWithFlags(&p->push_ready, hipEventDisableTiming));
+    return GMX_OK;
+}
+
+// peer_recv0/1[r]: rank r's landing zones as mapped here; my_offset[r]: where MY segment starts in them (rank r's
+// recv_offsets[me], elements); my_count[r] (optional): rank r's recv_counts[me], checked against what I would send
+extern "C" int gmx_pr_set_peers_packed(gmx_pr_t* p, void* const* peer_recv0, void* const* peer_recv1, const int64_t* my_offset, const int64_t* my_count) {
+    GMX_REQUIRE(p && peer_recv0 && peer_recv1 && my_offset, "NULL argument");
+    GMX_REQUIRE(p->packed, "the plan has no packed exchange lists");
+    for (int r = 0; r < p->nranks; r++)
+        if (r != p->rank) {
+            GMX_REQUIRE(peer_recv0[r] && peer_recv1[r], "peer %d: NULL landing zone", r);
+            GMX_REQUIRE(!my_count || my_count[r] == p->send_cnt[(size_t) r],
+                        "peer %d expects %lld entries from rank %d, which would send %lld", r, (long long) my_count[r], p->rank, (long long) p->send_cnt[(size_t) r]);
+        }
+    GMX_CHECK(pr_ensure_push_streams(p));
+    p->peer_rbuf[0].assign((char* const*) peer_recv0, (char* const*) peer_recv0 + p->nranks);
+    p->peer_rbuf[1].assign((char* const*) peer_recv1, (char* const*) peer_recv1 + p->nranks);
+    p->peer_roff.assign(my_offset, my_offset + p->nranks);
+    return GMX_OK;
+}
+
+// chunk boundaries inside the per-peer lists: sbound / rbound[r * (C + 1) + j] = first list index whose position is >= the
+// j-th boundary of the exchanged prefix (row order; chunk c in processing order covers j = C - 1 - c)
+static int64_t pr_chunk_bound(const gmx_pr* p, int j);
+static int pr_packed_bounds(gmx_pr* p) {
+    const int C = p->nchunks, N = p->nranks;
+    if (p->bound_chunks == C && !p->sbound.empty()) return GMX_OK;
+    std::vector<int64_t> q;
+    for (int dir = 0; dir < 2; dir++)
+        for (int r = 0; r < N; r++)
+            for (int j = 0; j <= C; j++) {
+                q.push_back(dir ? p->recv_off[(size_t) r] : p->send_off[(size_t) r]);
+                q.push_back(dir ? p->recv_cnt[(size_t) r] : p->send_cnt[(size_t) r]);
+                q.push_back(p->ns > 0 ? pr_chunk_bound(p, j) : (j == 0 ? 0 : p->exchange_count));
+            }
+    const int nq = (int) (q.size() / 3), half = nq / 2;
+    dbuf<int64_t> dq, dout;
+    GMX_CHECK(dq.alloc(q.size()));
+    GMX_CHECK(dout.alloc((size_t) nq));
+    GMX_HIP(hipMemcpy(dq.p, q.data(), sizeof(int64_t) * q.size(), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(pr_list_bounds_kernel, dim3((half + 63) / 64), dim3(64), 0, 0, (const int32_t*) p->slist.p, (const int64_t*) dq.p, half, dout.p);
+    hipLaunchKernelGGL(pr_list_bounds_kernel, dim3((half + 63) / 64), dim3(64), 0, 0, (const int32_t*) p->rlist.p, (const int64_t*) dq.p + 3 * half, half, dout.p + half);
+    std::vector<int64_t> h((size_t) nq);
+    GMX_HIP(hipMemcpy(h.data(), dout.p, sizeof(int64_t) * (size_t) nq, hipMemcpyDeviceToHost));
+    p->sbound.assign(h.begin(), h.begin() + half);
+    p->rbound.assign(h.begin() + half, h.end());
+    p->bound_chunks = C;
+    return GMX_OK;
+}
+
+// list index range of chunk `chunk` (-1: the whole list) for peer r
+static void pr_packed_range(const gmx_pr* p, bool recv, int r, int chunk, int64_t* lo, int64_t* hi) {
+    const int C = p->nchunks;
+    const std::vector<int64_t>& b = recv ? p->rbound : p->sbound;
+    const int j = chunk < 0 ? 0 : C - 1 - chunk, j1 = chunk < 0 ? C : j + 1;
+    *lo = b[(size_t) r * (C + 1) + j];
+    *hi = b[(size_t) r * (C + 1) + j1];
+}
+
+// pack the chunk's live entries of replica b for every peer and copy them into the peers' landing zones of parity b
+static int pr_push_packed_range(gmx_pr* p, int b, int chunk, hipStream_t s, int set) {
+    if (p->nranks == 1) return GMX_OK;
+    GMX_REQUIRE(p->packed && !p->peer_rbuf[0].empty(), "gmx_pr_set_peers_packed has not been called");
+    GMX_CHECK(pr_packed_bounds(p));
+    pr_pack_args a;
+    int64_t most = 0;
+    for (int q = 0; q < p->nranks; q++) {
+        a.off[q] = p->send_off[(size_t) q];
+        pr_packed_range(p, false, q, chunk, &a.lo[q], &a.hi[q]);
+        if (q == p->rank) a.hi[q] = a.lo[q] = 0;
+        most = std::max(most, a.hi[q] - a.lo[q]);
+    }
+    if (most > 0) {
+        const char* own = p->contrib[b].p + (size_t) p->row_lo * p->elem;
+        const dim3 grid((unsigned) grid_for(most, 256, 1024), (unsigned) p->nranks);
+        if (p->elem == 4) hipLaunchKernelGGL(pr_pack_kernel<float>, grid, dim3(256), 0, s, a, (const int32_t*) p->slist.p, (const float*) own, (float*) p->sbuf.p);
+        else hipLaunchKernelGGL(pr_pack_kernel<double>, grid, dim3(256), 0, s, a, (const int32_t*) p->slist.p, (const double*) own, (double*) p->sbuf.p);
+        GMX_HIP(hipGetLastError());
+    }
+    GMX_HIP(hipEventRecord(p->push_ready, s));
+    for (int i = 1; i < p->nranks; i++) {
+        const int q = (p->rank + i) % p->nranks;   // every rank starts with a different peer
+        GMX_HIP(hipStreamWaitEvent(p->push_stream[set][q], p->push_ready, 0));
+        const int64_t n = a.hi[q] - a.lo[q];
+        if (n > 0)
+            GMX_HIP(hipMemcpyAsync(p->peer_rbuf[b][q] + (size_t) (p->peer_roff[(size_t) q] + a.lo[q]) * p->elem,
+                                   p->sbuf.p + (size_t) (a.off[q] + a.lo[q]) * p->elem, (size_t) n * p->elem, hipMemcpyDeviceToDevice, p->push_stream[set][q]));
+    }
+    return GMX_OK;
+}
+
+extern "C" int gmx_pr_push_packed(gmx_pr_t* p, int chunk, void* stream) {
+    GMX_REQUIRE(p, "pr is NULL");
+    GMX_REQUIRE(chunk >= -1 && chunk < p->nchunks, "chunk %d out of range", chunk);
+    // chunk >= 0: the piece the running step has just finished (replica step_next); -1: the whole prefix of the current replica
+    return pr_push_packed_range(p, chunk < 0 ? p->cur : p->step_next, chunk, (hipStream_t) stream, chunk < 0 ? 0 : (chunk & 1));
+}
+
+// scatter what the peers packed for chunk `chunk` (-1: everything) from the landing zone of the current replica's parity
+// into the current replica (the one the next step reads).  Call after the barrier that follows the pushes.
+extern "C" int gmx_pr_unpack(gmx_pr_t* p, int chunk, void* stream) {
+    GMX_REQUIRE(p, "pr is NULL");
+    if (p->nranks == 1) return GMX_OK;
+    GMX_REQUIRE(p->packed, "the plan has no packed exchange lists");
+    GMX_REQUIRE(chunk >= -1 && chunk < p->nchunks, "chunk %d out of range", chunk);
+    GMX_CHECK(pr_packed_bounds(p));
+    pr_pack_args a;
+    int64_t most = 0;
+    for (int r = 0; r < p->nranks; r++) {
+        a.off[r] = p->recv_off[(size_t) r];
+        pr_packed_range(p, true, r, chunk, &a.lo[r], &a.hi[r]);
+        if (r == p->rank) a.hi[r] = a.lo[r] = 0;
+        most = std::max(most, a.hi[r] - a.lo[r]);
+    }
+    if (most == 0) return GMX_OK;
+    const int b = p->cur;
+    const dim3 grid((unsigned) grid_for(most, 256, 1024), (unsigned) p->nranks);
+    if (p->elem == 4) hipLaunchKernelGGL(pr_unpack_kernel<float>, grid, dim3(256), 0, (hipStream_t) stream, a, (const int32_t*) p->rlist.p, (const float*) p->rbuf[b].p, (float*) p->contrib[b].p, p->slice);
+    else hipLaunchKernelGGL(pr_unpack_kernel<double>, grid, dim3(256), 0, (hipStream_t) stream, a, (const int32_t*) p->rlist.p, (const double*) p->rbuf[b].p, (double*) p->contrib[b].p, p->slice);
+    GMX_HIP(hipGetLastError());
+    return GMX_OK;
+}
+
+// the positions (inside rank r's range) this rank reads: device pointer + count (for checks)
+extern "C" int gmx_pr_recv_list(gmx_pr_t* p, int r, void** dev_ptr, int64_t* count) {
+    GMX_REQUIRE(p && dev_ptr && count && r >= 0 && r < p->nranks, "bad argument");
+    GMX_REQUIRE(p->packed, "the plan has no packed exchange lists");
+    *dev_ptr = p->rlist.p + p->recv_off[(size_t) r];
+    *count = p->recv_cnt[(size_t) r];
+    return GMX_OK;
 }
 
 extern "C" int gmx_pr_contrib_slice(gmx_pr_t* p, void** dev_ptr, int64_t* count) {

@@ -77,6 +77,7 @@ struct gmx_pr_multi {
     std::vector<hipEvent_t> computed;     // [r * 2 + c]
     int home = 0;                         // device the caller's graph lives on
     bool verified = false;                // the first exchange has been checked against the owners' ranges (verify_replicas)
+    bool packed = false;                  // peer exchange of the packed lists (gmx_pr_push_packed / gmx_pr_unpack)
     ~gmx_pr_multi() {
         for (size_t r = 0; r < pr.size(); r++) {
             (void) hipSetDevice(dev[r]);
@@ -211,13 +212,30 @@ int gmx_pr_multi_create(gmx_graph* g, int elem, int nranks, gmx_pr_multi** out) 
                 hipEventCreateWithFlags(&m->done[r], hipEventDisableTiming) != hipSuccess) { gmx_set_error("stream/event creation failed"); st = GMX_ERR_HIP; break; }
         }
         if (st) break;
+        // "send only what is read": when every rank's plan has the lists, wire the landing zones (one process: raw pointers)
+        if (m->exchange == EX_PEER && nranks > 1 && nranks <= 16 && env_int("GMX_PUSH_PACKED", 1) != 0) {
+            std::vector<std::vector<int64_t>> roff((size_t) nranks, std::vector<int64_t>((size_t) nranks, 0)), rcnt = roff;
+            std::vector<void*> z0((size_t) nranks, nullptr), z1((size_t) nranks, nullptr);
+            bool ok = true;
+            for (int r = 0; r < nranks && ok; r++) {
+                int64_t bytes = 0;
+                ok = hipSetDevice(m->dev[r]) == hipSuccess && gmx_pr_packed_info(m->pr[r], nullptr, rcnt[(size_t) r].data(), roff[(size_t) r].data()) == GMX_OK &&
+                     gmx_pr_recv_buffers(m->pr[r], &z0[(size_t) r], &z1[(size_t) r], &bytes) == GMX_OK;
+            }
+            for (int r = 0; r < nranks && ok; r++) {
+                std::vector<int64_t> off((size_t) nranks, 0), cnt((size_t) nranks, 0);
+                for (int q = 0; q < nranks; q++) { off[(size_t) q] = roff[(size_t) q][(size_t) r]; cnt[(size_t) q] = rcnt[(size_t) q][(size_t) r]; }
+                ok = hipSetDevice(m->dev[r]) == hipSuccess && gmx_pr_set_peers_packed(m->pr[r], z0.data(), z1.data(), off.data(), cnt.data()) == GMX_OK;
+            }
+            m->packed = ok;
+        }
         // Peer copies + every in-edge binned: with GMX_PR_MULTI_PIPELINE=1 the step is cut in two row chunks and
         // pipelined (see pipelined_iteration).  Off by default: ONE host thread then issues ~480 HIP calls per
         // iteration for 8 ranks (16 launches, 112 copies on streams of their own, their events and waits) against ~130
         // for the step in one piece, and at ~5 us a call that is longer than the 0.4 ms the ranks compute -- measured
         // with 8 rank states on one GPU (RMAT-24, 50 iterations): 567 ms pipelined, 380 ms in one piece.  The
         // one-process-per-GPU driver (dist_pagerank.py) issues ~30 calls per rank and iteration and pipelines by default.
-        if (m->exchange == EX_PEER && nranks > 1 && env_int("GMX_PR_MULTI_PIPELINE", 0) != 0) {
+        if (m->exchange == EX_PEER && nranks > 1 && !m->packed && env_int("GMX_PR_MULTI_PIPELINE", 0) != 0) {
             bool ok = true;
             for (int r = 0; r < nranks && ok; r++) {
                 int classes = 0, chunks = 0;
@@ -280,6 +298,21 @@ static int exchange(gmx_pr_multi* m) {
     GMX_CHECK(gmx_pr_exchange_count(m->pr[0], &need));
     GMX_CHECK(gmx_pr_contrib_full(m->pr[0], &sp, &total));
     const size_t es = (size_t) m->elem;
+    if (m->exchange == EX_PEER && m->packed) {   // pack -> copy engines -> (all landed) -> unpack
+        for (int r = 0; r < m->nranks; r++) {
+            GMX_HIP(hipSetDevice(m->dev[r]));
+            GMX_CHECK(gmx_pr_push_packed(m->pr[r], -1, m->stream[r]));
+            GMX_CHECK(gmx_pr_push_join(m->pr[r], m->stream[r]));
+            GMX_HIP(hipEventRecord(m->done[r], m->stream[r]));
+        }
+        for (int q = 0; q < m->nranks; q++) {
+            GMX_HIP(hipSetDevice(m->dev[q]));
+            for (int r = 0; r < m->nranks; r++)
+                if (r != q) GMX_HIP(hipStreamWaitEvent(m->stream[q], m->done[r], 0));
+            GMX_CHECK(gmx_pr_unpack(m->pr[q], -1, m->stream[q]));
+        }
+        return GMX_OK;
+    }
     if (m->exchange == EX_PEER) {
         for (int r = 0; r < m->nranks; r++) {
             GMX_HIP(hipSetDevice(m->dev[r]));
@@ -330,6 +363,16 @@ __global__ void prm_compare_kernel(const uint32_t* __restrict__ a, const uint32_
     if (c) atomicAdd(bad, c);
 }
 
+__global__ void prm_compare_list_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const int32_t* __restrict__ list, int64_t n,
+                                        int words_per_elem, unsigned long long* __restrict__ bad) {
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    unsigned long long c = 0;
+    for (; i < n; i += stride)
+        for (int w = 0; w < words_per_elem; w++) c += a[(int64_t) list[i] * words_per_elem + w] != b[(int64_t) list[i] * words_per_elem + w];
+    if (c) atomicAdd(bad, c);
+}
+
 struct prm_event {   // released on every return path
     hipEvent_t e = nullptr;
     ~prm_event() { if (e) (void) hipEventDestroy(e); }
@@ -357,7 +400,14 @@ static int verify_replicas(gmx_pr_multi* m) {
             if (r == q) continue;
             const size_t at = (size_t) r * (size_t) slice * es;
             GMX_HIP(hipMemcpyPeer(tmp.p, m->dev[q], replica(m, r) + at, m->dev[r], words * 4));
-            hipLaunchKernelGGL(prm_compare_kernel, dim3(1024), dim3(256), 0, 0, (const uint32_t*) tmp.p, (const uint32_t*) (replica(m, q) + at), (int64_t) words, bad.p);
+            if (m->packed) {   // only the positions rank q reads have travelled
+                void* lp = nullptr;
+                int64_t ln = 0;
+                GMX_CHECK(gmx_pr_recv_list(m->pr[q], r, &lp, &ln));
+                hipLaunchKernelGGL(prm_compare_list_kernel, dim3(1024), dim3(256), 0, 0, (const uint32_t*) tmp.p, (const uint32_t*) (replica(m, q) + at),
+                                   (const int32_t*) lp, ln, (int) (es / 4), bad.p);
+            } else
+                hipLaunchKernelGGL(prm_compare_kernel, dim3(1024), dim3(256), 0, 0, (const uint32_t*) tmp.p, (const uint32_t*) (replica(m, q) + at), (int64_t) words, bad.p);
             GMX_HIP(hipDeviceSynchronize());
         }
         unsigned long long hb = 0;

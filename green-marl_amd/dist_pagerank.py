@@ -85,6 +85,18 @@ class GmxEngine:
     def push_join(self):
         self.state.push_join(None)
 
+    def unpack(self, chunk=-1):
+        self.state.unpack(chunk, None)
+
+    def packed(self):
+        return bool(getattr(self.state, "packed_push", False))
+
+    def recv_list(self, r):
+        return self._wrap(self.state.recv_list(r))
+
+    def exchange_bytes(self):
+        return self.state.exchange_bytes()
+
     def push_join_chunk(self, chunk, stream=None):
         self.state.push_join_chunk(chunk, stream)
 
@@ -170,18 +182,34 @@ class DistPageRank:
             raise RuntimeError("peer push unavailable on rank(s) %s: %s" % ([r for r, f in enumerate(flags) if not f], err))
         return False
 
+    def _packed(self):
+        return hasattr(self.engine, "packed") and self.engine.packed()
+
+    def _unpack(self, chunk=-1):
+        if self._packed():
+            self.engine.unpack(chunk)
+
     def _push_matches_collective(self):
+        """The replica of this rank against an all-gather of the owned prefixes; with the packed push only on the
+        positions this rank reads (the others are never sent)."""
         full = self.engine.contrib_full()
         mine = self.engine.contrib_slice()
         n = mine.numel()
         need = self.engine.exchange_count() if hasattr(self.engine, "exchange_count") else n
-        if self.barrier == "host":          # ranks sharing one GPU: the host barrier already ordered the copies
-            got = [torch.empty_like(mine[:need]).cpu() for _ in range(self.world)]
-            dist.all_gather(got, mine[:need].cpu(), group=self.group)
-            return all(torch.equal(got[r], full[r * n:r * n + need].cpu()) for r in range(self.world))
-        got = [torch.empty_like(mine[:need]) for _ in range(self.world)]
-        dist.all_gather(got, mine[:need].clone(), group=self.group)
-        return all(bool(torch.equal(got[r], full[r * n:r * n + need])) for r in range(self.world))
+        rank = dist.get_rank(self.group)
+        host = self.barrier == "host"       # ranks sharing one GPU: the host barrier already ordered the copies
+        got = [torch.empty_like(mine[:need]).cpu() if host else torch.empty_like(mine[:need]) for _ in range(self.world)]
+        dist.all_gather(got, mine[:need].cpu() if host else mine[:need].clone(), group=self.group)
+        for r in range(self.world):
+            have = full[r * n:r * n + need].cpu() if host else full[r * n:r * n + need]
+            if self._packed() and r != rank:
+                idx = self.engine.recv_list(r).long()
+                idx = idx.cpu() if host else idx
+                if not bool(torch.equal(got[r][idx], have[idx])):
+                    return False
+            elif not bool(torch.equal(got[r], have)):
+                return False
+        return True
 
     def _rank_barrier(self):
         """After a pushed step: nobody goes on before every rank's copies have completed.  Carries diff."""
@@ -231,6 +259,7 @@ class DistPageRank:
         eng = self.engine
         eng.step_gather(0)
         self._wait_early()
+        self._unpack(0)                    # (packed push) the tail chunk of the previous step, landed by now
         eng.step_gather(1)
         eng.step_chunk(0)
         eng.push_chunk(0)
@@ -242,10 +271,13 @@ class DistPageRank:
         else:
             eng.push_join_chunk(1)         # this stream waits for the hub copies only
         self._rank_barrier()
+        self._unpack(1)                    # (packed push) the hub chunk, which the next step's first gather reads
 
     def drain(self):
         """Everything issued so far (incl. the travelling tail chunk) ordered before what this stream does next."""
-        self._wait_early()
+        if self._early_work is not None:
+            self._wait_early()
+            self._unpack(0)
 
     def _step_pushed(self, chunks):
         eng = self.engine
@@ -256,6 +288,7 @@ class DistPageRank:
             eng.push_chunk(c)      # copies start when the chunk is done, the stream goes on with the next one
         eng.push_join()
         self._rank_barrier()
+        self._unpack(-1)
 
     def _exchange(self):
         if self.world == 1 and not self.always_exchange:
@@ -270,6 +303,8 @@ class DistPageRank:
                     raise
                 ok = 0
             self._rank_barrier()
+            if ok:
+                self._unpack(-1)
             if self.verify_push and not self.push_verified:
                 # once, outside any timed region: what the peers pushed into this replica must be what a
                 # collective all-gather of the same slices delivers; otherwise every rank falls back to it

@@ -52,6 +52,7 @@ EXPORTS = [
     "gmx_pr_set_chunks", "gmx_pr_num_chunks", "gmx_pr_chunk_range", "gmx_pr_step_chunk", "gmx_pr_contrib_next_full",
     "gmx_ipc_export", "gmx_ipc_open", "gmx_ipc_close", "gmx_pr_contrib_buffers", "gmx_pr_set_peers",
     "gmx_pr_push_chunk", "gmx_pr_push_current", "gmx_pr_push_join",
+    "gmx_pr_packed_info", "gmx_pr_recv_buffers", "gmx_pr_set_peers_packed", "gmx_pr_push_packed", "gmx_pr_unpack", "gmx_pr_recv_list",
     "gmx_pr_gather_classes", "gmx_pr_step_gather", "gmx_pr_push_join_chunk", "gmx_pr_gather_items",
     "gmx_pr_timing", "gmx_pr_kernel_time", "gmx_pr_kernel_name", "gmx_pr_default_options", "gmx_pr_cold_info",
 ]
@@ -132,6 +133,12 @@ def lib():
         L.gmx_pr_step_gather.argtypes = [vp, C.c_int, vp]
         L.gmx_pr_gather_items.argtypes = [vp, C.c_int, C.POINTER(i64)]
         L.gmx_pr_push_join_chunk.argtypes = [vp, C.c_int, vp]
+        L.gmx_pr_packed_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+        L.gmx_pr_recv_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
+        L.gmx_pr_set_peers_packed.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
+        L.gmx_pr_push_packed.argtypes = [vp, C.c_int, vp]
+        L.gmx_pr_unpack.argtypes = [vp, C.c_int, vp]
+        L.gmx_pr_recv_list.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(i64)]
         L.gmx_pr_set_chunks.argtypes = [vp, C.c_int]
         L.gmx_pr_num_chunks.argtypes = [vp, C.POINTER(C.c_int)]
         L.gmx_pr_chunk_range.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(i64)]
@@ -432,6 +439,24 @@ class BfsState:
             pass
 
 
+class _Handles(list):
+    """ipc_handles() of a rank: the replica handles as list items, the packed-exchange extras as attributes (picklable)."""
+
+    def __init__(self, *a):
+        super().__init__(*a)
+        self.landing = []
+        self.packed = None
+
+    def __reduce__(self):
+        return (_rebuild_handles, (list(self), self.landing, self.packed))
+
+
+def _rebuild_handles(items, landing, packed):
+    h = _Handles(items)
+    h.landing, h.packed = landing, packed
+    return h
+
+
 class PageRankState:
     """Device-resident PageRank stepping state (gmx_pr_*) for one rank of nranks."""
 
@@ -449,37 +474,112 @@ class PageRankState:
     def step(self, stream=None):
         _ck(lib().gmx_pr_step(self._h, stream))
 
-    # ---- peer push (gmx.h: exchange by direct copies into the peers' replicas) ----
-    def ipc_handles(self):
-        """hipIpc handles (bytes) of the two contribution replicas, to be opened by the other ranks."""
+    # ---- peer push (gmx.h: exchange by direct copies into the peers' replicas, packed when the plan has the lists) ----
+    def packed_info(self):
+        """{"send": [...], "recv": [...], "offset": [...]} (elements per peer) of the packed exchange, or None when the
+        plan has no lists (one rank, or not the degree order)."""
+        n = self.nranks
+        a, b, c = (C.c_int64 * n)(), (C.c_int64 * n)(), (C.c_int64 * n)()
+        if lib().gmx_pr_packed_info(self._h, a, b, c) != 0:
+            return None
+        return {"send": list(a), "recv": list(b), "offset": list(c)}
+
+    def _buffers(self, landing):
         b0, b1, n = C.c_void_p(), C.c_void_p(), C.c_int64(0)
-        _ck(lib().gmx_pr_contrib_buffers(self._h, C.byref(b0), C.byref(b1), C.byref(n)))
-        out = []
-        for b in (b0, b1):
+        _ck((lib().gmx_pr_recv_buffers if landing else lib().gmx_pr_contrib_buffers)(self._h, C.byref(b0), C.byref(b1), C.byref(n)))
+        return b0, b1
+
+    def ipc_handles(self):
+        """What the other ranks need to push into this one: hipIpc handles (bytes) of the two contribution replicas
+        [0], [1]; with a packed plan also ["landing"] (handles of the two landing zones) and ["packed"] (packed_info())."""
+        out = _Handles()
+        for b in self._buffers(False):
             h = C.create_string_buffer(IPC_HANDLE_BYTES)
             _ck(lib().gmx_ipc_export(b, h))
             out.append(h.raw)
+        info = self.packed_info()
+        if info is not None and os.environ.get("GMX_PUSH_PACKED", "1") != "0":
+            out.packed = info
+            for b in self._buffers(True):
+                h = C.create_string_buffer(IPC_HANDLE_BYTES)
+                _ck(lib().gmx_ipc_export(b, h))
+                out.landing.append(h.raw)
         return out
 
+    def _register_peers(self, ptrs, land, infos):
+        _ck(lib().gmx_pr_set_peers(self._h, ptrs[0], ptrs[1]))
+        self.packed_push = False
+        if land is not None:
+            off, cnt = (C.c_int64 * self.nranks)(), (C.c_int64 * self.nranks)()
+            for r in range(self.nranks):
+                if r != self.rank:
+                    off[r], cnt[r] = infos[r]["offset"][self.rank], infos[r]["recv"][self.rank]
+            _ck(lib().gmx_pr_set_peers_packed(self._h, land[0], land[1], off, cnt))
+            self.packed_push = True
+
     def set_peers(self, handles):
-        """handles[r] = rank r's ipc_handles() (own entry ignored): map them and register the pointers."""
+        """handles[r] = rank r's ipc_handles() (own entry ignored): map them and register the pointers.  The packed
+        push is used when every rank offers landing zones."""
         ptrs = [(C.c_void_p * self.nranks)(), (C.c_void_p * self.nranks)()]
+        packed = self.packed_info() is not None and all(getattr(h, "packed", None) is not None for h in handles)
+        land = [(C.c_void_p * self.nranks)(), (C.c_void_p * self.nranks)()] if packed else None
         self._peer_maps = []
         for r, hs in enumerate(handles):
             if r == self.rank:
                 continue
             for b in (0, 1):
-                q = C.c_void_p()
-                _ck(lib().gmx_ipc_open(C.create_string_buffer(hs[b], IPC_HANDLE_BYTES), C.byref(q)))
-                ptrs[b][r] = q.value
-                self._peer_maps.append(q.value)
-        _ck(lib().gmx_pr_set_peers(self._h, ptrs[0], ptrs[1]))
+                for dst, src in ((ptrs, hs), (land, hs.landing if packed else None)):
+                    if dst is None:
+                        continue
+                    q = C.c_void_p()
+                    _ck(lib().gmx_ipc_open(C.create_string_buffer(src[b], IPC_HANDLE_BYTES), C.byref(q)))
+                    dst[b][r] = q.value
+                    self._peer_maps.append(q.value)
+        self._register_peers(ptrs, land, [getattr(h, "packed", None) for h in handles])
+
+    def set_peers_local(self, states):
+        """The same wiring for rank states that live in THIS process (tests, one-GPU rehearsals): raw device pointers."""
+        ptrs = [(C.c_void_p * self.nranks)(), (C.c_void_p * self.nranks)()]
+        infos = [s.packed_info() for s in states]
+        packed = all(i is not None for i in infos) and os.environ.get("GMX_PUSH_PACKED", "1") != "0"
+        land = [(C.c_void_p * self.nranks)(), (C.c_void_p * self.nranks)()] if packed else None
+        for r, st in enumerate(states):
+            if r == self.rank:
+                continue
+            for dst, bufs in ((ptrs, st._buffers(False)), (land, st._buffers(True) if packed else None)):
+                if dst is not None:
+                    dst[0][r], dst[1][r] = bufs[0].value, bufs[1].value
+        self._register_peers(ptrs, land, infos)
 
     def push_chunk(self, chunk, stream=None):
-        _ck(lib().gmx_pr_push_chunk(self._h, chunk, stream))
+        if getattr(self, "packed_push", False):
+            _ck(lib().gmx_pr_push_packed(self._h, int(chunk), stream))
+        else:
+            _ck(lib().gmx_pr_push_chunk(self._h, chunk, stream))
 
     def push_current(self, stream=None):
-        _ck(lib().gmx_pr_push_current(self._h, stream))
+        if getattr(self, "packed_push", False):
+            _ck(lib().gmx_pr_push_packed(self._h, -1, stream))
+        else:
+            _ck(lib().gmx_pr_push_current(self._h, stream))
+
+    def unpack(self, chunk=-1, stream=None):
+        """After the barrier that follows the pushes: scatter what the peers packed (chunk, or -1 = everything) into the
+        replica the next step reads.  Nothing to do for the plain push."""
+        if getattr(self, "packed_push", False):
+            _ck(lib().gmx_pr_unpack(self._h, int(chunk), stream))
+
+    def recv_list(self, r):
+        """DevArray of the positions (inside rank r's range) this rank reads (packed plans)."""
+        p, n = C.c_void_p(), C.c_int64(0)
+        _ck(lib().gmx_pr_recv_list(self._h, int(r), C.byref(p), C.byref(n)))
+        return DevArray(p.value, n.value, "<i4")
+
+    def exchange_bytes(self):
+        """Bytes this rank sends per step: the packed lists if they are in use, else the exchanged prefix to every peer."""
+        if getattr(self, "packed_push", False):
+            return sum(self.packed_info()["send"]) * self.elem
+        return self.exchange_count() * (self.nranks - 1) * self.elem
 
     def push_join(self, stream=None):
         _ck(lib().gmx_pr_push_join(self._h, stream))

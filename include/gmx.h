@@ -244,6 +244,23 @@ int gmx_pr_set_peers(gmx_pr_t* p, void* const* peer_buf0, void* const* peer_buf1
 int gmx_pr_push_chunk(gmx_pr_t* p, int chunk, void* stream);
 int gmx_pr_push_current(gmx_pr_t* p, void* stream);
 int gmx_pr_push_join(gmx_pr_t* p, void* stream);
+/* Packed form of the push ("send only what is read").  Rank q reads source w iff w has an out-edge into a row q owns;
+ * on an 8-rank partition of RMAT-26 that is 46 % of the (source, reader) incidences of the full prefixes.  The plan of a
+ * rank (nranks > 1, degree order) holds, per peer, the sorted positions of ITS range that the peer reads and the
+ * positions of the peer's range that IT reads -- the same list on both sides by construction (gmx_pr_packed_info
+ * returns GMX_ERR_STATE when the plan has none).  gmx_pr_push_packed(c) gathers the chunk's entries of those lists into a
+ * staging buffer and copies each peer's piece into the peer's landing zone (double buffered by replica parity; wired
+ * up like the replicas: gmx_pr_recv_buffers -> gmx_ipc_export -> transport -> gmx_ipc_open -> gmx_pr_set_peers_packed
+ * with the offset of the caller's segment in each peer's zone = the peer's recv_offsets[caller]); chunk -1 pushes the
+ * current replica's whole prefix (after a reset).  After the per-step barrier gmx_pr_unpack(c) scatters what has landed
+ * into the replica the next step reads (c = -1: all chunks).  Positions nobody reads are never touched: afterwards the
+ * replicas agree with an all-gather only on the positions gmx_pr_recv_list names. */
+int gmx_pr_packed_info(gmx_pr_t* p, int64_t* send_counts, int64_t* recv_counts, int64_t* recv_offsets);   /* [nranks] each, elements */
+int gmx_pr_recv_buffers(gmx_pr_t* p, void** buf0, void** buf1, int64_t* bytes);
+int gmx_pr_set_peers_packed(gmx_pr_t* p, void* const* peer_recv0, void* const* peer_recv1, const int64_t* my_offset, const int64_t* my_count);
+int gmx_pr_push_packed(gmx_pr_t* p, int chunk, void* stream);
+int gmx_pr_unpack(gmx_pr_t* p, int chunk, void* stream);
+int gmx_pr_recv_list(gmx_pr_t* p, int r, void** dev_ptr, int64_t* count);
 /* Pipelined form of the pushed step (plans with every in-edge binned: gmx_pr_gather_classes returns 2, else 0).
  * Phase 1 of the binned sweep is the only part of a step that reads the peers' contributions, and most of its work
  * sits in the tiles of the hub sources, whose contributions are the small LAST chunk of every rank's exchange.  So:

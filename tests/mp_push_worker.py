@@ -33,6 +33,7 @@ def main():
     assert eng.set_chunks(chunks) == chunks
     pr = DistPageRank(eng, exchange="push", barrier="host")
     assert pr.exchange == "push"
+    assert eng.packed() == (os.environ.get("GMX_PUSH_PACKED", "1") != "0")     # the packed push unless switched off
     piped = []
     if binned:
         assert eng.gather_classes() == 2 and pr._early_group is not None

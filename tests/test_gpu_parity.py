@@ -648,7 +648,100 @@ def test_pagerank_pipelined_gather_order(gmx, scale, nranks, elem, monkeypatch):
     g.free()
 
 
-@pytest.mark.parametrize("world,chunks,elem,binned", [(3, 2, 8, ""), (2, 1, 4, ""), (3, 2, 4, "binned"), (2, 2, 8, "binned"), (2, 1, 4, "binned")])
+@pytest.mark.parametrize("scale,nranks,chunks,elem", [(16, 2, 1, 8), (18, 4, 2, 4), (17, 3, 2, 8), (18, 8, 2, 4), (20, 8, 1, 4)])
+def test_pagerank_packed_exchange_in_one_process(gmx, scale, nranks, chunks, elem, monkeypatch):
+    """"Send only what is read" (gmx_pr_push_packed / gmx_pr_unpack): N rank states of one process wired to each other's
+    landing zones, stepped chunk by chunk with the library's own pack -> copy -> unpack, against the same states
+    exchanging the full prefixes by hand.  The ranks must be bit-identical (an unread position never enters a sum), the
+    two views of every list must agree (what r sends to q is what q expects from r), and on RMAT the packed volume must
+    be well below the full one from 4 ranks up."""
+    import torch
+    monkeypatch.setenv("GMX_PR_COLD", "0")
+    og = po.rmat_graph(scale, permute=True)
+    g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+    options = gmx.GMX_PR_RELABEL | gmx.GMX_PR_HOT_LDS | gmx.GMX_PR_SLICED | gmx.GMX_PR_COLD_PB
+    iters = 5
+
+    def make():
+        states = [gmx.PageRankState(g, elem, r, nranks, options) for r in range(nranks)]
+        for s_ in states:
+            assert s_.set_chunks(chunks) == chunks
+        return states
+
+    def finish(states):
+        out = np.zeros(og.N, dtype=np.float64 if elem == 8 else np.float32)
+        for s_ in states:
+            s_.download(out)
+        d = sum(s_.diff() for s_ in states)
+        for s_ in states:
+            s_.free()
+        return out, d
+
+    # (1) the reference run: full prefixes copied by hand
+    states = make()
+    need = states[0].exchange_count()
+    n = torch.as_tensor(states[0].contrib_slice(), device="cuda").numel()
+    for s_ in states:
+        s_.reset(0.85)
+
+    def full_exchange():
+        fulls = [torch.as_tensor(s_.contrib_full(), device="cuda") for s_ in states]
+        for dst in fulls:
+            for r, src in enumerate(fulls):
+                if dst is not src:
+                    dst[r * n:r * n + need].copy_(src[r * n:r * n + need])
+        torch.cuda.synchronize()
+    full_exchange()
+    for _ in range(iters):
+        for s_ in states:
+            s_.step()
+        full_exchange()
+    want, want_diff = finish(states)
+    # (2) the packed run
+    states = make()
+    infos = [s_.packed_info() for s_ in states]
+    assert all(i is not None for i in infos)
+    for r in range(nranks):
+        for q in range(nranks):
+            assert infos[r]["send"][q] == infos[q]["recv"][r], (r, q)      # both ends hold the same list length
+            if r != q:                                                      # ... and the same positions
+                a = torch.as_tensor(states[q].recv_list(r), device="cuda")
+                assert a.numel() == infos[r]["send"][q] and bool((a[1:] > a[:-1]).all()) and (a.numel() == 0 or int(a[-1]) < need)
+    for s_ in states:
+        s_.set_peers_local(states)
+        assert s_.packed_push
+        s_.reset(0.85)
+    for s_ in states:
+        s_.push_current()
+        s_.push_join()
+    torch.cuda.synchronize()
+    for s_ in states:
+        s_.unpack(-1)
+    torch.cuda.synchronize()
+    for _ in range(iters):
+        for c in range(chunks):
+            for s_ in states:
+                s_.step_chunk(c)
+                s_.push_chunk(c)
+        for s_ in states:
+            s_.push_join()
+        torch.cuda.synchronize()              # the per-step barrier of this single-process rehearsal
+        for c in range(chunks):
+            for s_ in states:
+                s_.unpack(c)
+        torch.cuda.synchronize()
+    sent = sum(s_.exchange_bytes() for s_ in states)
+    full = nranks * (nranks - 1) * need * elem
+    got, got_diff = finish(states)
+    g.free()
+    assert np.array_equal(got, want) and got_diff == want_diff
+    assert sent <= full
+    if nranks >= 4 and scale >= 18:
+        assert sent < 0.8 * full, (sent, full)
+
+
+@pytest.mark.parametrize("world,chunks,elem,binned", [(3, 2, 8, ""), (2, 1, 4, ""), (3, 2, 4, "binned"), (2, 2, 8, "binned"), (2, 1, 4, "binned"),
+                                                      (3, 2, 4, "binned-plain"), (2, 1, 8, "plain")])
 def test_peer_push_exchange_between_processes(gmx, world, chunks, elem, binned):
     """The N > 1 exchange by direct copies into the peers' hipIpc-mapped replicas, with real processes (one
     per rank, sharing this box's single GPU; see tests/mp_push_worker.py).  binned: plans with every in-edge
@@ -662,8 +755,11 @@ def test_peer_push_exchange_between_processes(gmx, world, chunks, elem, binned):
     s.close()
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mp_push_worker.py")
     procs = []
+    plain = "plain" in binned            # the full-prefix push; otherwise the packed one (the default when the plans have lists)
+    binned = "binned" if "binned" in binned else ""
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   GMX_PUSH_PACKED="0" if plain else "1")
         procs.append(subprocess.Popen([sys.executable, worker, "15", str(chunks), str(elem), "8", binned], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
