@@ -27,6 +27,66 @@ void gmx_set_error(const char* fmt, ...) {
 extern "C" const char* gmx_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------ device
+// ------------------------------------------------------------------ workspace (see gmx_internal.h)
+namespace {
+struct ws_chunk { char* base; size_t cap; int device; };
+struct ws_state {
+    std::vector<ws_chunk> chunks;
+    size_t cur = 0, off = 0;
+};
+ws_state g_ws;
+constexpr size_t WS_ALIGN = 512;
+}   // namespace
+
+void* gmx_ws_alloc(size_t bytes) {
+    bytes = (bytes + WS_ALIGN - 1) / WS_ALIGN * WS_ALIGN;
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    for (;;) {
+        if (g_ws.cur < g_ws.chunks.size()) {
+            ws_chunk& c = g_ws.chunks[g_ws.cur];
+            if (c.device == dev && g_ws.off + bytes <= c.cap) {
+                void* p = c.base + g_ws.off;
+                g_ws.off += bytes;
+                return p;
+            }
+            g_ws.cur++;       // does not fit (or another device's chunk): try the next one
+            g_ws.off = 0;
+            continue;
+        }
+        // a new chunk: as large as everything held so far (256 MiB .. 32 GiB), so that a build's many buffers share a few
+        size_t held = 0;
+        for (const ws_chunk& c : g_ws.chunks) held += c.cap;
+        size_t want = held < ((size_t) 256 << 20) ? ((size_t) 256 << 20) : held > ((size_t) 32 << 30) ? ((size_t) 32 << 30) : held;
+        ws_chunk c{nullptr, bytes > want ? bytes : want, dev};
+        hipError_t e = hipMalloc((void**) &c.base, c.cap);
+        if (e != hipSuccess) {
+            gmx_set_error("workspace: hipMalloc(%zu bytes) failed: %s", c.cap, hipGetErrorString(e));
+            return nullptr;
+        }
+        g_ws.chunks.push_back(c);
+    }
+}
+gmx_ws_mark gmx_ws_top() { return {g_ws.cur, g_ws.off}; }
+void gmx_ws_rewind(gmx_ws_mark m) {
+    g_ws.cur = m.chunk;
+    g_ws.off = m.off;
+}
+extern "C" int gmx_workspace_release(void) {
+    for (ws_chunk& c : g_ws.chunks) {
+        (void) hipSetDevice(c.device);
+        (void) hipFree(c.base);
+    }
+    g_ws.chunks.clear();
+    g_ws.cur = g_ws.off = 0;
+    return GMX_OK;
+}
+extern "C" int64_t gmx_workspace_bytes(void) {
+    size_t t = 0;
+    for (const ws_chunk& c : g_ws.chunks) t += c.cap;
+    return (int64_t) t;
+}
+
 extern "C" int gmx_device_count(int* count) {
     GMX_REQUIRE(count, "count is NULL");
     int n = 0;
@@ -196,8 +256,9 @@ __global__ void rows_unsorted_kernel(const uint64_t* __restrict__ keys, int64_t 
 
 int gmx_csr_from_keys(uint64_t* keys, uint64_t* keys_alt, int64_t V, int64_t E,
                       int32_t* begin, int32_t* idx, hipStream_t stream, int32_t* slots) {
+    gmx_ws_scope ws;
     const uint64_t* sorted = keys;
-    dbuf<int32_t> iota;
+    wbuf<int32_t> iota;
     if (slots) {
         GMX_CHECK(iota.alloc((size_t) (E ? E : 1)));
         hipLaunchKernelGGL(iota_i32_kernel, dim3(grid_for(E)), dim3(256), 0, stream, E > 1 ? iota.p : slots, E);
@@ -205,7 +266,7 @@ int gmx_csr_from_keys(uint64_t* keys, uint64_t* keys_alt, int64_t V, int64_t E,
     if (E > 1) {
         unsigned end_bit = 32 + (unsigned) gmx_bits_for(V);
         size_t tmp_bytes = 0;
-        dbuf<char> tmp;
+        wbuf<char> tmp;
         if (slots) {   // stable: equal (row, col) keys keep their input order
             GMX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_alt, iota.p, slots, (size_t) E, 0u, end_bit, stream));
             GMX_CHECK(tmp.alloc(tmp_bytes));
@@ -231,7 +292,7 @@ int gmx_csr_from_keys(uint64_t* keys, uint64_t* keys_alt, int64_t V, int64_t E,
 // Build forward (and reverse) CSR of g from device keys (row<<32|col), consuming them.
 // sorted_csr (optional): the uploaded CSR the keys were made from; when its rows turn out to be in order already it
 // becomes the forward CSR as it is (no sort, identity e_idx2idx)
-static int build_from_forward_keys(gmx_graph* g, dbuf<uint64_t>& keys, dbuf<uint64_t>& alt, bool want_reverse, bool keep_order = false,
+static int build_from_forward_keys(gmx_graph* g, wbuf<uint64_t>& keys, wbuf<uint64_t>& alt, bool want_reverse, bool keep_order = false,
                                    dbuf<int32_t>* up_begin = nullptr, dbuf<int32_t>* up_idx = nullptr) {
     hipStream_t s = 0;
     int32_t* slots = nullptr;
@@ -279,6 +340,7 @@ static int check_sizes(int64_t V, int64_t E) {
 extern "C" int gmx_graph_upload(const gmx_edge_t* begin, const gmx_node_t* node_idx,
                                 const gmx_edge_t* r_begin, const gmx_node_t* r_node_idx,
                                 int64_t V, int64_t E, uint32_t flags, gmx_graph_t** out) {
+    gmx_ws_scope ws;
     GMX_REQUIRE(out, "out is NULL");
     *out = nullptr;
     GMX_CHECK(check_sizes(V, E));
@@ -295,7 +357,7 @@ extern "C" int gmx_graph_upload(const gmx_edge_t* begin, const gmx_node_t* node_
         if ((flags & GMX_GRAPH_SORT_ROWS) || (want_rev && !r_begin)) {
             // go through keys: sorts rows and/or builds the reverse CSR on the device
             dbuf<int32_t> tb, ti;
-            dbuf<uint64_t> keys, alt;
+            wbuf<uint64_t> keys, alt;
             if ((st = tb.alloc((size_t) V + 1)) || (st = ti.alloc((size_t) E)) ||
                 (st = keys.alloc((size_t) E)) || (st = alt.alloc((size_t) E))) break;
             if (hipMemcpy(tb.p, begin, sizeof(int32_t) * ((size_t) V + 1), hipMemcpyHostToDevice) != hipSuccess ||
@@ -334,6 +396,7 @@ extern "C" int gmx_graph_upload(const gmx_edge_t* begin, const gmx_node_t* node_
 
 extern "C" int gmx_graph_from_edges(const gmx_node_t* src, const gmx_node_t* dst,
                                     int64_t V, int64_t E, uint32_t flags, gmx_graph_t** out) {
+    gmx_ws_scope ws;
     GMX_REQUIRE(out, "out is NULL");
     *out = nullptr;
     GMX_CHECK(check_sizes(V, E));
@@ -346,8 +409,8 @@ extern "C" int gmx_graph_from_edges(const gmx_node_t* src, const gmx_node_t* dst
     (void) hipGetDevice(&g->device);
     int st = GMX_OK;
     do {
-        dbuf<int32_t> ds, dd;
-        dbuf<uint64_t> keys, alt;
+        wbuf<int32_t> ds, dd;
+        wbuf<uint64_t> keys, alt;
         if ((st = ds.alloc((size_t) E)) || (st = dd.alloc((size_t) E)) ||
             (st = keys.alloc((size_t) E)) || (st = alt.alloc((size_t) E))) break;
         if (E && (hipMemcpy(ds.p, src, sizeof(int32_t) * (size_t) E, hipMemcpyHostToDevice) != hipSuccess ||
@@ -474,6 +537,7 @@ __global__ void apply_perm_kernel(int32_t* __restrict__ a, int64_t n, const int3
 
 extern "C" int gmx_graph_create_rmat(int64_t N, int64_t M, long seed, double a, double b, double c,
                                      int permute, uint32_t flags, gmx_graph_t** out) {
+    gmx_ws_scope ws;
     GMX_REQUIRE(out, "out is NULL");
     *out = nullptr;
     GMX_CHECK(check_sizes(N, M));
@@ -494,8 +558,8 @@ extern "C" int gmx_graph_create_rmat(int64_t N, int64_t M, long seed, double a, 
     (void) hipGetDevice(&g->device);
     int st = GMX_OK;
     do {
-        dbuf<int32_t> src, dst;
-        dbuf<int64_t> bad, slots;
+        wbuf<int32_t> src, dst;
+        wbuf<int64_t> bad, slots;
         dbuf<unsigned long long> nbad;
         size_t bad_cap = (size_t) M + 16;  // worst case: every attempt of a round is a self loop
         if (bad_cap > (1u << 24)) bad_cap = (size_t) (M / 16) + (1u << 20);
@@ -521,7 +585,7 @@ extern "C" int gmx_graph_create_rmat(int64_t N, int64_t M, long seed, double a, 
                 // edge multiset, but keep it deterministic: sort the slot list
                 size_t tb = 0;
                 if ((he = rocprim::radix_sort_keys(nullptr, tb, bad.p, slots.p, (size_t) nb)) != hipSuccess) break;
-                dbuf<char> tmp;
+                wbuf<char> tmp;
                 if ((st = tmp.alloc(tb))) break;
                 if ((he = rocprim::radix_sort_keys((void*) tmp.p, tb, bad.p, slots.p, (size_t) nb)) != hipSuccess) break;
                 if ((he = hipDeviceSynchronize()) != hipSuccess) break;
@@ -547,7 +611,7 @@ extern "C" int gmx_graph_create_rmat(int64_t N, int64_t M, long seed, double a, 
                 P[k] = P[i];
                 P[i] = tmp;
             }
-            dbuf<int32_t> dP;
+            wbuf<int32_t> dP;
             if ((st = dP.alloc((size_t) N))) break;
             if (hipMemcpy(dP.p, P.data(), sizeof(int32_t) * (size_t) N, hipMemcpyHostToDevice) != hipSuccess) {
                 gmx_set_error("H2D copy of permutation failed");
@@ -559,7 +623,7 @@ extern "C" int gmx_graph_create_rmat(int64_t N, int64_t M, long seed, double a, 
             if (hipDeviceSynchronize() != hipSuccess) { gmx_set_error("apply_perm failed"); st = GMX_ERR_HIP; break; }
         }
 
-        dbuf<uint64_t> keys, alt;
+        wbuf<uint64_t> keys, alt;
         if ((st = keys.alloc((size_t) M)) || (st = alt.alloc((size_t) M))) break;
         if ((st = gmx_keys_from_edges(src.p, dst.p, M, false, nullptr, keys.p, 0))) break;
         if (hipDeviceSynchronize() != hipSuccess) { gmx_set_error("keys_from_edges failed"); st = GMX_ERR_HIP; break; }
@@ -593,6 +657,7 @@ struct key_is_edge {
 // Undirected simple version of g: every edge in both directions, duplicates and self loops removed
 // (the measurement preparation of the triangle-counting config).
 extern "C" int gmx_graph_symmetrize(const gmx_graph_t* g, gmx_graph_t** out) {
+    gmx_ws_scope ws;
     GMX_REQUIRE(g && out, "NULL argument");
     *out = nullptr;
     GMX_REQUIRE(2 * g->E < (1LL << 31), "symmetrised edge count exceeds int32 edge_t");
@@ -602,7 +667,7 @@ extern "C" int gmx_graph_symmetrize(const gmx_graph_t* g, gmx_graph_t** out) {
     (void) hipGetDevice(&h->device);
     int st = GMX_OK;
     do {
-        dbuf<uint64_t> fwd, both, alt, uniq;
+        wbuf<uint64_t> fwd, both, alt, uniq;
         dbuf<int64_t> count;
         if ((st = fwd.alloc((size_t) E)) || (st = both.alloc((size_t) 2 * E)) || (st = alt.alloc((size_t) 2 * E)) ||
             (st = uniq.alloc((size_t) 2 * E)) || (st = count.alloc(1))) break;
@@ -614,12 +679,12 @@ extern "C" int gmx_graph_symmetrize(const gmx_graph_t* g, gmx_graph_t** out) {
             rocprim::double_buffer<uint64_t> db(both.p, alt.p);
             size_t tb = 0;
             hipError_t he = rocprim::radix_sort_keys(nullptr, tb, db, (size_t) (2 * E), 0u, 64u, 0);
-            dbuf<char> tmp;
+            wbuf<char> tmp;
             if (he == hipSuccess && (st = tmp.alloc(tb))) break;
             if (he == hipSuccess) he = rocprim::radix_sort_keys((void*) tmp.p, tb, db, (size_t) (2 * E), 0u, 64u, 0);
             size_t ub = 0;
             if (he == hipSuccess) he = rocprim::unique(nullptr, ub, db.current(), uniq.p, count.p, (size_t) (2 * E), rocprim::equal_to<uint64_t>(), 0);
-            dbuf<char> tmp2;
+            wbuf<char> tmp2;
             if (he == hipSuccess && (st = tmp2.alloc(ub))) break;
             if (he == hipSuccess) he = rocprim::unique((void*) tmp2.p, ub, db.current(), uniq.p, count.p, (size_t) (2 * E), rocprim::equal_to<uint64_t>(), 0);
             if (he == hipSuccess) he = hipMemcpy(&n, count.p, sizeof(int64_t), hipMemcpyDeviceToHost);
@@ -700,11 +765,12 @@ __global__ void iota_kernel(int32_t* __restrict__ a, int64_t n) {
 }
 
 extern "C" int gmx_graph_reverse_edge_map(const gmx_graph_t* g, gmx_edge_t* e_rev2idx) {
+    gmx_ws_scope ws;
     GMX_REQUIRE(g && e_rev2idx, "NULL argument");
     if (g->E == 0) return GMX_OK;
     hipStream_t s = 0;
-    dbuf<uint64_t> keys, keys2;
-    dbuf<int32_t> val, val2;
+    wbuf<uint64_t> keys, keys2;
+    wbuf<int32_t> val, val2;
     GMX_CHECK(keys.alloc((size_t) g->E));
     GMX_CHECK(keys2.alloc((size_t) g->E));
     GMX_CHECK(val.alloc((size_t) g->E));
@@ -714,7 +780,7 @@ extern "C" int gmx_graph_reverse_edge_map(const gmx_graph_t* g, gmx_edge_t* e_re
     size_t tb = 0;
     const unsigned end_bit = 32 + (unsigned) gmx_bits_for(g->V);
     GMX_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys2.p, val.p, val2.p, (size_t) g->E, 0u, end_bit, s));
-    dbuf<char> tmp;
+    wbuf<char> tmp;
     GMX_CHECK(tmp.alloc(tb));
     GMX_HIP(rocprim::radix_sort_pairs((void*) tmp.p, tb, keys.p, keys2.p, val.p, val2.p, (size_t) g->E, 0u, end_bit, s));
     GMX_HIP(hipMemcpy(e_rev2idx, val2.p, sizeof(int32_t) * (size_t) g->E, hipMemcpyDeviceToHost));

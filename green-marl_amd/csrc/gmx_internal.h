@@ -69,6 +69,41 @@ struct dbuf {
     T* take() { T* q = p; p = nullptr; n = 0; return q; }
 };
 
+// ---- workspace: where the big temporaries of graph construction and plan builds live ----
+// Device memory that has just been freed is not free: the driver wipes it before it hands it out again, and a
+// hipMalloc that needs such memory waits for the wipe -- measured here as stalls of 1-2.4 s inside an RMAT-26 plan build
+// (an 8 GB allocation behind the ~100 GB of temporaries the graph construction had freed), against 0.2 s without them.
+// So the multi-gigabyte temporaries are carved from chunks that stay allocated for the life of the process (stack
+// discipline: gmx_ws_scope rewinds on exit; a buffer's release() is a no-op) and nothing big is ever freed between a
+// graph's construction and its plans.  gmx_workspace_release() (gmx.h) gives the chunks back.
+struct gmx_ws_mark { size_t chunk, off; };
+void* gmx_ws_alloc(size_t bytes);
+gmx_ws_mark gmx_ws_top();
+void gmx_ws_rewind(gmx_ws_mark m);
+struct gmx_ws_scope {
+    gmx_ws_mark m;
+    gmx_ws_scope() : m(gmx_ws_top()) {}
+    ~gmx_ws_scope() { gmx_ws_rewind(m); }
+    gmx_ws_scope(const gmx_ws_scope&) = delete;
+    gmx_ws_scope& operator=(const gmx_ws_scope&) = delete;
+};
+// dbuf's interface on workspace memory (valid until the enclosing gmx_ws_scope ends)
+template <typename T>
+struct wbuf {
+    T* p = nullptr;
+    size_t n = 0;
+    wbuf() {}
+    wbuf(const wbuf&) = delete;
+    wbuf& operator=(const wbuf&) = delete;
+    int alloc(size_t count) {
+        n = count;
+        p = (T*) gmx_ws_alloc((count ? count : 1) * sizeof(T));
+        if (!p) { n = 0; return GMX_ERR_NOMEM; }
+        return GMX_OK;
+    }
+    void release() { p = nullptr; n = 0; }
+};
+
 struct gmx_bfs;
 
 struct gmx_graph {

@@ -1281,6 +1281,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
     hipStream_t s = 0;
     int st = GMX_OK;
     gmx_tick tick("pr plan");
+    gmx_ws_scope ws;   // the temporaries of the build are workspace memory (wbuf)
     do {
         if ((st = p->inv.alloc((size_t) p->rows)) || (st = p->outdeg.alloc((size_t) p->rows))) break;
         if (p->rows && (hipMemset(p->inv.p, 0xff, sizeof(int32_t) * (size_t) p->rows) != hipSuccess ||
@@ -1290,23 +1291,23 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
             p->rb = g->r_begin.p;
             p->ridx = g->r_node_idx.p;
             p->El = E;
-            dbuf<int32_t> perm;
+            wbuf<int32_t> perm;
             if ((st = perm.alloc((size_t) V))) break;
             hipLaunchKernelGGL(pr_perm_kernel, dim3(grid_for(V)), dim3(256), 0, s, (const int32_t*) nullptr, V, p->slice, nranks, 0, perm.p);
             hipLaunchKernelGGL(pr_owned_kernel, dim3(grid_for(V)), dim3(256), 0, s, perm.p, g->begin.p, V, p->row_lo, p->rows, p->inv.p, p->outdeg.p);
             if (hipStreamSynchronize(s) != hipSuccess) { gmx_set_error("pr plan (identity) failed"); st = GMX_ERR_HIP; break; }
         } else {
-            dbuf<int32_t> perm;
+            wbuf<int32_t> perm;
             if ((st = perm.alloc((size_t) V))) break;
             if (relabel) {
-                dbuf<uint32_t> key, key2;
-                dbuf<int32_t> id, order;
+                wbuf<uint32_t> key, key2;
+                wbuf<int32_t> id, order;
                 if ((st = key.alloc((size_t) V)) || (st = key2.alloc((size_t) V)) || (st = id.alloc((size_t) V)) ||
                     (st = order.alloc((size_t) V))) break;
                 hipLaunchKernelGGL(pr_degkey_kernel, dim3(grid_for(V)), dim3(256), 0, s, g->begin.p, V, key.p, id.p);
                 size_t tb = 0;
                 hipError_t he = rocprim::radix_sort_pairs(nullptr, tb, key.p, key2.p, id.p, order.p, (size_t) V, 0u, 32u, s);
-                dbuf<char> tmp;
+                wbuf<char> tmp;
                 if (he == hipSuccess && (st = tmp.alloc(tb))) break;
                 if (he == hipSuccess) he = rocprim::radix_sort_pairs((void*) tmp.p, tb, key.p, key2.p, id.p, order.p, (size_t) V, 0u, 32u, s);
                 if (he == hipSuccess) {
@@ -1316,7 +1317,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 if (he != hipSuccess) { gmx_set_error("pr plan: degree sort failed: %s", hipGetErrorString(he)); st = GMX_ERR_HIP; break; }
                 // vertices with out-degree 0 are never gathered; in the degree order they form the tail of every
                 // rank's range, so only a prefix of each range has to travel between ranks
-                dbuf<int64_t> nzd;
+                wbuf<int64_t> nzd;
                 if ((st = nzd.alloc(2))) break;
                 hipLaunchKernelGGL(pr_key32_bound_kernel, dim3(1), dim3(64), 0, s, (const uint32_t*) key2.p, V, 0x7fffffffu, nzd.p);
                 int64_t nz = V;
@@ -1330,7 +1331,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
             }
             hipLaunchKernelGGL(pr_owned_kernel, dim3(grid_for(V)), dim3(256), 0, s, perm.p, g->begin.p, V, p->row_lo, p->rows, p->inv.p, p->outdeg.p);
             // keys (perm[dst] << 32 | perm[src]) from the reverse CSR, sorted; then cut the owned rows
-            dbuf<uint64_t> keys, alt;
+            wbuf<uint64_t> keys, alt;
             if ((st = keys.alloc((size_t) E)) || (st = alt.alloc((size_t) E))) break;
             if ((st = gmx_keys_from_csr(g->r_begin.p, g->r_node_idx.p, V, E, false, perm.p, keys.p, s))) break;
             const uint64_t* sorted = keys.p;
@@ -1349,12 +1350,12 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
             if (unsorted_ok) {
                 if (nranks == 1) hb[1] = E;
                 else {
-                    dbuf<int64_t> nsel;
+                    wbuf<int64_t> nsel;
                     if ((st = nsel.alloc(1))) break;
                     pr_row_in_range pred{(uint64_t) p->row_lo << 32, (uint64_t) (p->row_lo + p->rows) << 32};
                     size_t tb = 0;
                     hipError_t he = rocprim::select(nullptr, tb, (const uint64_t*) keys.p, alt.p, nsel.p, (size_t) E, pred, s);
-                    dbuf<char> tmp;
+                    wbuf<char> tmp;
                     if (he == hipSuccess && (st = tmp.alloc(tb))) break;
                     if (he == hipSuccess) he = rocprim::select((void*) tmp.p, tb, (const uint64_t*) keys.p, alt.p, nsel.p, (size_t) E, pred, s);
                     if (he == hipSuccess) he = hipMemcpy(&hb[1], nsel.p, sizeof(int64_t), hipMemcpyDeviceToHost);
@@ -1367,7 +1368,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 size_t tb = 0;
                 unsigned end_bit = 32 + (unsigned) gmx_bits_for(p->Vpad);
                 hipError_t he = rocprim::radix_sort_keys(nullptr, tb, db, (size_t) E, 0u, end_bit, s);
-                dbuf<char> tmp;
+                wbuf<char> tmp;
                 if (he == hipSuccess && (st = tmp.alloc(tb))) break;
                 if (he == hipSuccess) he = rocprim::radix_sort_keys((void*) tmp.p, tb, db, (size_t) E, 0u, end_bit, s);
                 if (he == hipSuccess) he = hipStreamSynchronize(s);
@@ -1375,7 +1376,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 sorted = db.current();
             }
             if (!unsorted_ok) {
-                dbuf<int64_t> bounds;
+                wbuf<int64_t> bounds;
                 if ((st = bounds.alloc(2))) break;
                 hipLaunchKernelGGL(pr_key_bound_kernel, dim3(1), dim3(64), 0, s, sorted, E,
                                    (uint64_t) p->row_lo << 32, (uint64_t) (p->row_lo + p->rows) << 32, bounds.p);
@@ -1411,12 +1412,12 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                     Ec = p->El;
                 } else if (p->cold_T >= 0) {
                     uint64_t* other = (sorted == keys.p) ? alt.p : keys.p;
-                    dbuf<int64_t> nsel;
+                    wbuf<int64_t> nsel;
                     if ((st = nsel.alloc(1))) break;
                     pr_is_hot_key pred{(uint32_t) p->slice, (uint32_t) p->cold_T};
                     size_t tb = 0;
                     hipError_t he = rocprim::partition(nullptr, tb, own, other, nsel.p, (size_t) p->El, pred, s);
-                    dbuf<char> tmp;
+                    wbuf<char> tmp;
                     if (he == hipSuccess && (st = tmp.alloc(tb))) break;
                     if (he == hipSuccess) he = rocprim::partition((void*) tmp.p, tb, own, other, nsel.p, (size_t) p->El, pred, s);
                     int64_t nh = 0;
@@ -1429,9 +1430,9 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 }
                 // group the kept keys by source slice (stable 1-pass radix sort on the slice number)
                 const int64_t El = p->Eh;
-                dbuf<uint8_t> sk, sk2;
-                dbuf<uint64_t> vals;
-                dbuf<int64_t> off;
+                wbuf<uint8_t> sk, sk2;
+                wbuf<uint64_t> vals;
+                wbuf<int64_t> off;
                 if ((st = sk.alloc((size_t) El)) || (st = sk2.alloc((size_t) El)) || (st = vals.alloc((size_t) El)) ||
                     (st = off.alloc(PR_MAX_SLICES + 1))) break;
                 hipLaunchKernelGGL(pr_slice_key_kernel, dim3(grid_for(El)), dim3(256), 0, s, hk, El, ns, sk.p);
@@ -1439,7 +1440,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 if (El > 0) {
                     size_t tb = 0;
                     he = rocprim::radix_sort_pairs(nullptr, tb, sk.p, sk2.p, hk, vals.p, (size_t) El, 0u, 3u, s);
-                    dbuf<char> tmp;
+                    wbuf<char> tmp;
                     if (he == hipSuccess && (st = tmp.alloc(tb))) break;
                     if (he == hipSuccess) he = rocprim::radix_sort_pairs((void*) tmp.p, tb, sk.p, sk2.p, hk, vals.p, (size_t) El, 0u, 3u, s);
                     if (he == hipSuccess) he = hipStreamSynchronize(s);
@@ -1453,19 +1454,19 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                     if ((st = p->sl_is_active.alloc((size_t) (rows ? rows : 1))) || (st = p->sl_active.alloc((size_t) (rows ? rows : 1)))) break;
                     if (hipMemsetAsync(p->sl_is_active.p, 0, (size_t) (rows ? rows : 1), s) != hipSuccess) { gmx_set_error("pr plan: memset failed"); st = GMX_ERR_HIP; break; }
                     if (p->El > 0) hipLaunchKernelGGL(pr_mark_active_kernel, dim3(grid_for(p->El)), dim3(256), 0, s, own, p->El, p->row_lo, p->sl_is_active.p);
-                    dbuf<int64_t> cnt;
+                    wbuf<int64_t> cnt;
                     if ((st = cnt.alloc(1))) break;
                     size_t tb = 0;
                     rocprim::counting_iterator<int32_t> ids(0);
                     he = rocprim::select(nullptr, tb, ids, (const uint8_t*) p->sl_is_active.p, p->sl_active.p, cnt.p, (size_t) rows, s);
-                    dbuf<char> tmp3;
+                    wbuf<char> tmp3;
                     if (he == hipSuccess && (st = tmp3.alloc(tb))) break;
                     if (he == hipSuccess) he = rocprim::select((void*) tmp3.p, tb, ids, (const uint8_t*) p->sl_is_active.p, p->sl_active.p, cnt.p, (size_t) rows, s);
                     if (he == hipSuccess) he = hipMemcpy(&p->sl_nactive, cnt.p, sizeof(int64_t), hipMemcpyDeviceToHost);
                     if (he != hipSuccess) { gmx_set_error("pr plan: active-row list failed: %s", hipGetErrorString(he)); st = GMX_ERR_HIP; break; }
                 }
                 // compact rows: one (slice,row) pair per row that has at least one edge in the slice
-                dbuf<int32_t> flag, pos;
+                wbuf<int32_t> flag, pos;
                 if ((st = flag.alloc((size_t) El + 1)) || (st = pos.alloc((size_t) El + 1)) || (st = p->sl_ridx.alloc((size_t) El))) break;
                 hipLaunchKernelGGL(pr_slice_flag_kernel, dim3(grid_for(El)), dim3(256), 0, s, (const uint64_t*) vals.p,
                                    (const uint8_t*) sk2.p, El, flag.p, p->sl_ridx.p);
@@ -1474,7 +1475,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 if (El > 0) {
                     size_t tb = 0;
                     he = rocprim::exclusive_scan(nullptr, tb, flag.p, pos.p, 0, (size_t) El, rocprim::plus<int32_t>(), s);
-                    dbuf<char> tmp2;
+                    wbuf<char> tmp2;
                     if (he == hipSuccess && (st = tmp2.alloc(tb))) break;
                     if (he == hipSuccess) he = rocprim::exclusive_scan((void*) tmp2.p, tb, flag.p, pos.p, 0, (size_t) El, rocprim::plus<int32_t>(), s);
                     if (he == hipSuccess) he = hipStreamSynchronize(s);
@@ -1497,7 +1498,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 hipLaunchKernelGGL(pr_slice_pairs_kernel, dim3(grid_for(El)), dim3(256), 0, s, (const uint64_t*) vals.p,
                                    (const uint8_t*) sk2.p, (const int32_t*) flag.p, (const int32_t*) pos.p, (const int64_t*) off.p,
                                    El, p->row_lo, p->sl_rowid.p, p->sl_rb.p);
-                dbuf<int32_t> index_of_row;
+                wbuf<int32_t> index_of_row;
                 {   // name the compact rows by their position in active[] and make the dense per-active-row copies
                     const size_t na = (size_t) (p->sl_nactive ? p->sl_nactive : 1);
                     if ((st = index_of_row.alloc((size_t) (rows ? rows : 1))) || (st = p->sl_outdeg_c.alloc(na)) ||
@@ -1514,10 +1515,10 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 }
                 if (nranks > 1 && relabel && nranks <= 16 && !getenv("GMX_PR_NO_PACKED")) {
                     // ---- packed exchange lists (see the struct) ----
-                    dbuf<unsigned int> rmask;
-                    dbuf<uint8_t> mark;
-                    dbuf<int64_t> nsel;
-                    dbuf<char> tmp;
+                    wbuf<unsigned int> rmask;
+                    wbuf<uint8_t> mark;
+                    wbuf<int64_t> nsel;
+                    wbuf<char> tmp;
                     if ((st = rmask.alloc((size_t) rows)) || (st = mark.alloc((size_t) p->Vpad)) || (st = nsel.alloc(1))) break;
                     hipError_t he = hipMemsetAsync(rmask.p, 0, sizeof(unsigned int) * (size_t) rows, s);
                     if (he == hipSuccess) he = hipMemsetAsync(mark.p, 0, (size_t) p->Vpad, s);
@@ -1525,7 +1526,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                     hipLaunchKernelGGL(pr_reader_mask_kernel, dim3(grid_for((E + 15) / 16)), dim3(256), 0, s, g->begin.p, g->node_idx.p, V, E,
                                        (const int32_t*) perm.p, p->slice, p->row_lo, rows, rmask.p);
                     if (p->El > 0) hipLaunchKernelGGL(pr_mark_sources_kernel, dim3(grid_for(p->El)), dim3(256), 0, s, own, p->El, mark.p);
-                    dbuf<int32_t> sl_tmp, rl_tmp;
+                    wbuf<int32_t> sl_tmp, rl_tmp;
                     if ((st = sl_tmp.alloc((size_t) p->exchange_count * nranks + 1)) || (st = rl_tmp.alloc((size_t) p->exchange_count * nranks + 1))) break;
                     p->send_cnt.assign((size_t) nranks, 0); p->send_off.assign((size_t) nranks + 1, 0);
                     p->recv_cnt.assign((size_t) nranks, 0); p->recv_off.assign((size_t) nranks + 1, 0);
@@ -1566,7 +1567,7 @@ extern "C" int gmx_pr_create(gmx_graph_t* g, int elem_bytes, int rank, int nrank
                 }
                 tick.mark("owned rows, active rows");
                 if (p->cold_T >= 0) {   // tile- and bin-major streams of the binned edges
-                    dbuf<int32_t> deg_by_id;
+                    wbuf<int32_t> deg_by_id;
                     if ((st = deg_by_id.alloc((size_t) p->Vpad))) break;
                     if (hipMemsetAsync(deg_by_id.p, 0xff, sizeof(int32_t) * (size_t) p->Vpad, s) != hipSuccess) { gmx_set_error("pr plan: memset failed"); st = GMX_ERR_HIP; break; }
                     hipLaunchKernelGGL(pr_deg_by_id_kernel, dim3(grid_for(V)), dim3(256), 0, s, (const int32_t*) perm.p, g->begin.p, V, deg_by_id.p);

@@ -1328,7 +1328,7 @@ static int prc_env_int(const char* name, int dflt) {
 }
 
 // exclusive prefix sums of n int32 values (in != out)
-static hipError_t prc_exscan(const int32_t* in, int32_t* out, int64_t n, dbuf<char>& tmp, hipStream_t s) {
+static hipError_t prc_exscan(const int32_t* in, int32_t* out, int64_t n, wbuf<char>& tmp, hipStream_t s) {
     size_t tb = 0;
     hipError_t e = rocprim::exclusive_scan(nullptr, tb, in, out, 0, (size_t) n, rocprim::plus<int32_t>(), s);
     if (e != hipSuccess) return e;
@@ -1340,7 +1340,7 @@ static hipError_t prc_exscan(const int32_t* in, int32_t* out, int64_t n, dbuf<ch
 }
 
 // inclusive prefix sums of n int32 values (in != out)
-static hipError_t prc_inscan(const int32_t* in, int32_t* out, int64_t n, dbuf<char>& tmp, hipStream_t s) {
+static hipError_t prc_inscan(const int32_t* in, int32_t* out, int64_t n, wbuf<char>& tmp, hipStream_t s) {
     size_t tb = 0;
     hipError_t e = rocprim::inclusive_scan(nullptr, tb, in, out, (size_t) n, rocprim::plus<int32_t>(), s);
     if (e != hipSuccess) return e;
@@ -1380,12 +1380,13 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
     // 256 (189 tiles) -> 1.46, every pair tile -> 1.43: the (class, bin) sub-cells stay fuller than feared, 1.51 M -> 1.61 M cells)
     int st = GMX_OK;
     gmx_tick tick("cold plan");
-    dbuf<uint64_t> k1, k2;
-    dbuf<int32_t> cflag, cincl, ps, pincl, pstart, plen, ppos, pos, endf, endpre, first, pfirst, groups, c1raw, c1, vtab, delta, counts, id, order2, groups2,
+    gmx_ws_scope ws;   // every temporary below is workspace memory
+    wbuf<uint64_t> k1, k2;
+    wbuf<int32_t> cflag, cincl, ps, pincl, pstart, plen, ppos, pos, endf, endpre, first, pfirst, groups, c1raw, c1, vtab, delta, counts, id, order2, groups2,
         c2s, c2, tab2, tstat;
-    dbuf<uint32_t> ckey, key2, key2s;
-    dbuf<uint8_t> mode;
-    dbuf<char> tmp;
+    wbuf<uint32_t> ckey, key2, key2s;
+    wbuf<uint8_t> mode;
+    wbuf<char> tmp;
     uint64_t* sk = nullptr;
     std::vector<int32_t> hts, hvt, hdelta, vstart, h2;
     std::vector<uint8_t> hmode;
@@ -1622,7 +1623,7 @@ int pr_cold_create(const uint64_t* keys, int64_t Ec, const pr_cold_params& prm, 
         PRC_TRY(hipMemcpy(c->torg.p, horg.data(), sizeof(int32_t) * horg.size(), hipMemcpyHostToDevice), "copy");
     }
     if (prm.deg_by_id) {   // per tile: the largest out-degree of its sources
-        dbuf<int32_t> tmax;
+        wbuf<int32_t> tmax;
         PRC_ALLOC(tmax, c->ntiles);
         PRC_TRY(hipMemsetAsync(tmax.p, 0, sizeof(int32_t) * (size_t) c->ntiles, s), "memset");
         const int64_t nids = (int64_t) prm.nranks * prm.slice;

@@ -41,7 +41,7 @@ class DeviceInfo(C.Structure):
 
 
 EXPORTS = [
-    "gmx_last_error", "gmx_device_count", "gmx_set_device", "gmx_device_info", "gmx_copy_bandwidth",
+    "gmx_workspace_bytes", "gmx_workspace_release", "gmx_last_error", "gmx_device_count", "gmx_set_device", "gmx_device_info", "gmx_copy_bandwidth",
     "gmx_graph_upload", "gmx_graph_from_edges", "gmx_graph_create_rmat", "gmx_graph_free", "gmx_graph_symmetrize",
     "gmx_graph_num_nodes", "gmx_graph_num_edges", "gmx_graph_download", "gmx_graph_edge_order",
     "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_bfs_levels", "gmx_bc", "gmx_sssp", "gmx_avg_teen_cnt", "gmx_conduct", "gmx_triangle_counting", "gmx_triangle_counting_part", "gmx_triangle_counting_cn", "gmx_common_nbrs", "gmx_common_nbr_counts", "gmx_graph_reverse_edge_map",
@@ -77,6 +77,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
         L.gmx_last_error.restype = C.c_char_p
+        L.gmx_workspace_bytes.restype = C.c_int64
         L.gmx_device_count.argtypes = [C.POINTER(C.c_int)]
         L.gmx_set_device.argtypes = [C.c_int]
         L.gmx_device_info.argtypes = [C.POINTER(DeviceInfo)]

@@ -62,6 +62,13 @@ int gmx_device_info(gmx_device_info_t* info);
  * the achievable HBM ceiling bench.py reports next to the data-sheet peak. */
 int gmx_copy_bandwidth(int64_t bytes, int iters, double* gbs);
 
+/* The multi-gigabyte temporaries of graph construction and plan builds come from a workspace that stays allocated for
+ * the life of the process (freed device memory is wiped by the driver before reuse, and allocations that need it stall
+ * for seconds at RMAT-26 sizes).  gmx_workspace_bytes: what it holds now; gmx_workspace_release: give it back (e.g. once
+ * every graph and plan is built; anything built later allocates it again). */
+int64_t gmx_workspace_bytes(void);
+int gmx_workspace_release(void);
+
 /* ---- graph: replaces the emitted prologue `G.freeze(); G.make_reverse_edges();
  *      [G.do_semi_sort();]` + Shoal copy-in (gm_cpp_gen.cc:1307-1368, 670-778) ---- */
 
