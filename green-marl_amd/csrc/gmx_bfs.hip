@@ -1582,3 +1582,10 @@ extern "C" int gmx_conduct(gmx_graph_t* g, const int32_t* member_host, int32_t n
     }
     return GMX_OK;
 }
+
+// Loads this translation unit's code object (the HIP runtime does that lazily, at the first launch of one of its kernels:
+// tens of milliseconds that would otherwise fall into the first timed call) -- called once from the graph constructors.
+void gmx_touch_bfs() {
+    hipFuncAttributes attr;
+    (void) hipFuncGetAttributes(&attr, (const void*) bfs_totals_kernel);
+}

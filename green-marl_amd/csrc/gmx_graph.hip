@@ -330,7 +330,17 @@ static int build_from_forward_keys(gmx_graph* g, wbuf<uint64_t>& keys, wbuf<uint
     return GMX_OK;
 }
 
+void gmx_warm_modules() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    gmx_touch_pagerank();
+    gmx_touch_pr_cold();
+    gmx_touch_bfs();
+}
+
 static int check_sizes(int64_t V, int64_t E) {
+    gmx_warm_modules();   // (every graph constructor passes through here)
     GMX_REQUIRE(V >= 0 && V < (1LL << 31) - 1, "V=%lld out of int32 node_t range", (long long) V);
     GMX_REQUIRE(E >= 0 && E < (1LL << 31), "E=%lld out of int32 edge_t range", (long long) E);
     return GMX_OK;

@@ -212,6 +212,11 @@ struct gmx_tick {
     }
 };
 
+void gmx_touch_pagerank();
+void gmx_touch_pr_cold();
+void gmx_touch_bfs();
+void gmx_warm_modules();   // once per process: load every translation unit's code object (see gmx_touch_*)
+
 static inline int gmx_bits_for(int64_t v) {  // bits needed to represent values in [0, v)
     int b = 1;
     while ((1LL << b) < v && b < 32) b++;
