@@ -26,6 +26,10 @@
 #include <dlfcn.h>
 #include <stdlib.h>
 
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 // ---- the few RCCL entry points used, resolved at run time ----
 typedef void* rccl_comm_t;
 struct rccl_api {
@@ -478,6 +482,80 @@ static int pipelined_drain(gmx_pr_multi* m) {
     return GMX_OK;
 }
 
+// ---- the iteration loop with one host thread per rank (packed peer exchange) ----
+// One thread issuing every rank's launches, copies and event calls is host-bound long before 8 GPUs are busy: ~370 HIP
+// calls per iteration for 8 ranks at 3-5 us each is 1-2 ms, against the ~0.3 ms a rank computes.  The emitted entry is
+// called from one thread and opens its own parallel regions (#pragma omp parallel in the reference's emission,
+// gm_cpp_gen.cc:1874-1909); here the "parallel region" is one std::thread per rank for the duration of the loop, each
+// issuing only its own device's ~45 calls.  Two host barriers per iteration: A -- every rank has recorded its
+// "my pieces are on their way" event before anybody waits on it; B -- every rank's diff is on the host.
+namespace {
+struct host_barrier {
+    std::mutex mu;
+    std::condition_variable cv;
+    int n, waiting = 0;
+    unsigned long long gen = 0;
+    explicit host_barrier(int n_) : n(n_) {}
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        const unsigned long long g = gen;
+        if (++waiting == n) { waiting = 0; gen++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+}   // namespace
+
+static int threaded_loop(gmx_pr_multi* m, double e, int32_t max_iter, double* diff_out, int32_t* cnt_out) {
+    const int N = m->nranks;
+    host_barrier bar(N);
+    std::vector<int> status((size_t) N, GMX_OK);
+    std::vector<std::string> message((size_t) N);
+    std::vector<double> dr((size_t) N, 0.0);
+    double diff = 0.0;
+    int32_t cnt = 0;
+    auto body = [&](int r) {
+        int st = hipSetDevice(m->dev[r]) == hipSuccess ? GMX_OK : GMX_ERR_HIP;
+        int32_t it = 0;   // iterations done (the same number in every thread)
+        for (;;) {
+            // every thread runs every barrier of an iteration, whatever its own status: nobody is left waiting
+            if (st == GMX_OK) st = gmx_pr_step(m->pr[r], m->stream[r]);
+            if (st == GMX_OK) st = gmx_pr_push_packed(m->pr[r], -1, m->stream[r]);
+            if (st == GMX_OK) st = gmx_pr_push_join(m->pr[r], m->stream[r]);
+            if (st == GMX_OK && hipEventRecord(m->done[r], m->stream[r]) != hipSuccess) st = GMX_ERR_HIP;
+            bar.wait();                                                   // A
+            for (int q = 0; q < N && st == GMX_OK; q++)
+                if (q != r && hipStreamWaitEvent(m->stream[r], m->done[q], 0) != hipSuccess) st = GMX_ERR_HIP;
+            if (st == GMX_OK) st = gmx_pr_unpack(m->pr[r], -1, m->stream[r]);
+            if (st == GMX_OK) st = gmx_pr_diff(m->pr[r], m->stream[r], &dr[(size_t) r]);   // (synchronises the rank's stream)
+            if (st != GMX_OK && status[(size_t) r] == GMX_OK) { status[(size_t) r] = st; message[(size_t) r] = gmx_last_error(); }
+            bar.wait();                                                   // B
+            bool go;
+            {   // every thread forms the same sum in rank order and takes the same decision
+                double t = 0.0;
+                bool bad = false;
+                for (int q = 0; q < N; q++) { t += dr[(size_t) q]; bad = bad || status[(size_t) q] != GMX_OK; }
+                it++;
+                go = !bad && (t > e) && (it < max_iter);
+                if (r == 0) { diff = t; cnt = it; }
+            }
+            if (!go) break;   // (dr[] is next written behind barrier A of the next iteration, which needs every thread)
+        }
+    };
+    std::vector<std::thread> workers;
+    for (int r = 1; r < N; r++) workers.emplace_back(body, r);
+    body(0);
+    for (std::thread& t : workers) t.join();
+    (void) hipSetDevice(m->dev[0]);
+    *diff_out = diff;
+    *cnt_out = cnt;
+    for (int r = 0; r < N; r++)
+        if (status[(size_t) r] != GMX_OK) {
+            gmx_set_error("rank %d: %s", r, message[(size_t) r].c_str());
+            return status[(size_t) r];
+        }
+    return GMX_OK;
+}
+
 int gmx_pr_multi_run(gmx_pr_multi* m, double e, double d, int32_t max_iter, void* rank_host, gmx_stats_t* stats) {
     double diff = 0.0;
     int32_t cnt = 0;
@@ -496,7 +574,9 @@ int gmx_pr_multi_run(gmx_pr_multi* m, double e, double d, int32_t max_iter, void
         if (!m->verified && m->nranks > 1 && (st = verify_replicas(m))) break;
         GMX_HIP(hipSetDevice(m->dev[0]));
         (void) hipEventRecord(ev0, m->stream[0]);
-        do {
+        if (m->packed && !m->pipelined && m->exchange == EX_PEER && m->nranks > 1 && env_int("GMX_PR_MULTI_THREADS", 1) != 0) {
+            if ((st = threaded_loop(m, e, max_iter, &diff, &cnt))) break;
+        } else do {
             if (m->pipelined) {
                 if ((st = pipelined_iteration(m, cnt == 0))) break;
             } else {
