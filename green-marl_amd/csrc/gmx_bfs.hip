@@ -1113,46 +1113,145 @@ static int bfs_run(gmx_bfs* b, gmx_node_t root) {
     return GMX_OK;
 }
 
-// visit_fw of comp_BC (bc.gm:18-21):  v.sigma = Sum(w: v.UpNbrs){ w.sigma }
+// ---- the visits of an InBFS traversal (gm_bfs_template.h:69-312: visit_fw / visit_rv, as gm_cpp_gen_bfs.cc:88-275 emits
+// them) as device functors.  A VISIT is: for every vertex v of a level, S = Sum over its UpNbrs (in-neighbours one level
+// closer, DIR = -1, through the reverse CSR) or DownNbrs (out-neighbours one level deeper, DIR = +1: the template's
+// is_down_edge) of term(v, w), then finish(v, S).  A new InBFS app is two structs with
+//     static constexpr int DIR;  float prep(v) const;  float term(float prep_of_v, w) const;  void finish(v, S) const;
+// handed to bfs_sweep(): comp_BC below is the first.
+// The Float sums must round exactly like the sequential emission -- S = S + term, one term after the other in row-slot
+// order -- so the ADDS of a row are a serial chain whatever is done.  Everything else is parallel: a wave takes 64 rows of
+// the level; rows shorter than BFS_VISIT_SMALL are walked one per lane; the longer rows go onto the level's list and are
+// taken, one wave per row, 64 slots at a time: coalesced loads of the slots, the neighbours' levels and values gathered
+// by 64 lanes at once, the filter as one ballot, each lane's term computed with the emission's own float expression,
+// and the passing terms added in slot order through v_readlane (hub rows of 10^5 slots were one lane's dependent-load
+// chain in round 2: comp_BC on RMAT-24, five seeds, 1.69 s -> 0.04 s).
+#define BFS_VISIT_SMALL 32
+
+// S = S + term for every set bit of `pass`, ascending lane = ascending slot (wave-uniform result)
+__device__ __forceinline__ float bfs_ordered_add(float S, float term, unsigned long long pass) {
+    while (pass) {
+        const int j = __builtin_ctzll(pass);
+        S = S + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, term), j));
+        pass &= pass - 1;
+    }
+    return S;
+}
+
+// the wave's long rows go onto the level's list (one atomic per wave), to be taken by bfs_visit_big_kernel
+__device__ __forceinline__ void bfs_append_big(bool is_big, int32_t v, int lane, int32_t* __restrict__ big_list, unsigned int* __restrict__ big_count) {
+    const unsigned long long m = __ballot(is_big);
+    if (!m) return;
+    unsigned int at = 0;
+    if (lane == 0) at = atomicAdd(big_count, (unsigned int) __builtin_popcountll(m));
+    at = __builtin_amdgcn_readfirstlane(at);
+    if (is_big) big_list[at + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = v;
+}
+
+// level `level` = order[lo, hi); begin / idx: the reverse CSR for DIR = -1, the forward CSR for DIR = +1
+template <class Visit>
 __global__ void __launch_bounds__(BFS_THREADS)
-bc_forward_kernel(const int32_t* __restrict__ order, int64_t lo, int64_t hi, int32_t level, const int32_t* __restrict__ dist,
-                  const int32_t* __restrict__ r_begin, const int32_t* __restrict__ r_node_idx, int32_t skip, float* __restrict__ sigma) {
-    int64_t i = lo + (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
-    for (; i < hi; i += stride) {
-        const int32_t v = order[i];
-        if (v == skip) continue;
-        float S1 = 0.0f;
-        for (int32_t w_idx = r_begin[v]; w_idx < r_begin[v + 1]; w_idx++) {
-            const int32_t w = r_node_idx[w_idx];
-            if (dist[w] != level - 1) continue;
-            S1 = S1 + sigma[w];
+bfs_visit_kernel(const int32_t* __restrict__ order, int64_t lo, int64_t hi, int32_t level, const int32_t* __restrict__ dist,
+                 const int32_t* __restrict__ begin, const int32_t* __restrict__ idx, int32_t skip, Visit vis,
+                 int32_t* __restrict__ big_list, unsigned int* __restrict__ big_count) {
+    const int lane = threadIdx.x & 63;
+    int64_t base = lo + ((int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
+    const int64_t stride = (int64_t) gridDim.x * (blockDim.x >> 6) * 64;
+    for (; base < hi; base += stride) {   // (wave-uniform)
+        const int64_t i = base + lane;
+        int32_t v = -1, rb = 0, deg = 0;
+        if (i < hi) {
+            v = order[i];
+            if (v == skip) v = -1;
+            else { rb = begin[v]; deg = begin[v + 1] - rb; }
         }
-        sigma[v] = S1;
+        if (v >= 0 && deg < BFS_VISIT_SMALL) {
+            const float pv = vis.prep(v);
+            float S = 0.0f;
+            for (int32_t e = rb; e < rb + deg; e++) {
+                const int32_t w = idx[e];
+                if (dist[w] != level + Visit::DIR) continue;
+                S = S + vis.term(pv, w);
+            }
+            vis.finish(v, S);
+        }
+        bfs_append_big(v >= 0 && deg >= BFS_VISIT_SMALL, v, lane, big_list, big_count);
     }
 }
 
-// visit_rv (bc.gm:22-29):  v.delta = Sum(w: v.DownNbrs){ v.sigma / w.sigma * (1 + w.delta) };  v.BC += v.delta
+// the long rows of the level, one wave per row (any wave takes any row: a level's hubs run side by side)
+template <class Visit>
 __global__ void __launch_bounds__(BFS_THREADS)
-bc_reverse_kernel(const int32_t* __restrict__ order, int64_t lo, int64_t hi, int32_t level, const int32_t* __restrict__ dist,
-                  const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx, int32_t skip,
-                  const float* __restrict__ sigma, float* __restrict__ delta, float* __restrict__ bc) {
-    int64_t i = lo + (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
-    for (; i < hi; i += stride) {
-        const int32_t v = order[i];
-        if (v == skip) continue;
-        float S2 = 0.0f;
-        const float sv = sigma[v];
-        for (int32_t w_idx = begin[v]; w_idx < begin[v + 1]; w_idx++) {
-            const int32_t w = node_idx[w_idx];
-            if (dist[w] != level + 1) continue;   // !is_down_edge(w_idx)
-            S2 = S2 + sv / sigma[w] * (1 + delta[w]);
+bfs_visit_big_kernel(const int32_t* __restrict__ big_list, const unsigned int* __restrict__ big_count, int32_t level, const int32_t* __restrict__ dist,
+                     const int32_t* __restrict__ begin, const int32_t* __restrict__ idx, Visit vis) {
+    const int lane = threadIdx.x & 63;
+    const unsigned int n = *big_count, nwaves = gridDim.x * (blockDim.x >> 6);
+    for (unsigned int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < n; k += nwaves) {   // (wave-uniform)
+        const int32_t vb = big_list[k], rbb = begin[vb], degb = begin[vb + 1] - rbb;
+        const float pv = vis.prep(vb);
+        float S = 0.0f;
+        for (int32_t c = 0; c < degb; c += 64) {
+            const int32_t e = c + lane;
+            bool pass = false;
+            float term = 0.0f;
+            if (e < degb) {
+                const int32_t w = idx[rbb + e];
+                pass = dist[w] == level + Visit::DIR;
+                if (pass) term = vis.term(pv, w);
+            }
+            S = bfs_ordered_add(S, term, __ballot(pass));
         }
-        delta[v] = S2;
-        bc[v] = bc[v] + S2;
+        if (lane == 0) vis.finish(vb, S);
     }
 }
+
+// one level of a visit: the short rows and the list of the long ones, then the long ones
+template <class Visit>
+static int bfs_visit_level(gmx_graph* g, gmx_bfs* b, const int32_t* order, int64_t lo, int64_t hi, int32_t level, int32_t skip, const Visit& vis,
+                           int32_t* big_list, unsigned int* big_count) {
+    if (hi <= lo) return GMX_OK;
+    const int32_t* begin = Visit::DIR < 0 ? g->r_begin.p : g->begin.p;
+    const int32_t* idx = Visit::DIR < 0 ? g->r_node_idx.p : g->node_idx.p;
+    GMX_HIP(hipMemsetAsync(big_count, 0, sizeof(unsigned int), 0));
+    hipLaunchKernelGGL((bfs_visit_kernel<Visit>), dim3(grid_for(hi - lo)), dim3(BFS_THREADS), 0, 0, order, lo, hi, level, (const int32_t*) b->dist.p,
+                       begin, idx, skip, vis, big_list, big_count);
+    hipLaunchKernelGGL((bfs_visit_big_kernel<Visit>), dim3(grid_for(hi - lo, 4, 1024)), dim3(BFS_THREADS), 0, 0, (const int32_t*) big_list,
+                       (const unsigned int*) big_count, level, (const int32_t*) b->dist.p, begin, idx, vis);
+    return GMX_OK;
+}
+
+// InBFS(v: G.Nodes From s) { visit_fw } InReverse { visit_rv }: the forward visit level by level from the root, the
+// reverse visit from the deepest level back (gm_bfs_template.h:69-312); `ord` holds the traversal's level order
+template <class VisitFw, class VisitRv>
+static int bfs_sweep(gmx_graph* g, gmx_bfs* b, const bfs_order& ord, int32_t skip, const VisitFw& fw, const VisitRv& rv, int32_t* big_list, unsigned int* big_count) {
+    for (int32_t l = 0; l < ord.levels; l++)
+        GMX_CHECK(bfs_visit_level(g, b, (const int32_t*) ord.order.p, ord.h_off[(size_t) l], ord.h_off[(size_t) l + 1], l, skip, fw, big_list, big_count));
+    for (int32_t l = ord.levels - 1; l >= 0; l--)
+        GMX_CHECK(bfs_visit_level(g, b, (const int32_t*) ord.order.p, ord.h_off[(size_t) l], ord.h_off[(size_t) l + 1], l, skip, rv, big_list, big_count));
+    GMX_HIP(hipGetLastError());
+    return GMX_OK;
+}
+
+// comp_BC's two visits (apps/src/bc.gm:16-29)
+struct bc_visit_fw {   // v.sigma = Sum(w: v.UpNbrs){ w.sigma }
+    static constexpr int DIR = -1;
+    float* sigma;
+    __device__ float prep(int32_t) const { return 0.0f; }
+    __device__ float term(float, int32_t w) const { return sigma[w]; }
+    __device__ void finish(int32_t v, float S) const { sigma[v] = S; }
+};
+struct bc_visit_rv {   // v.delta = Sum(w: v.DownNbrs){ v.sigma / w.sigma * (1 + w.delta) };  v.BC += v.delta
+    static constexpr int DIR = +1;
+    const float* sigma;
+    float* delta;
+    float* bc;
+    __device__ float prep(int32_t v) const { return sigma[v]; }
+    __device__ float term(float sv, int32_t w) const { return sv / sigma[w] * (1 + delta[w]); }
+    __device__ void finish(int32_t v, float S) const {
+        delta[v] = S;
+        bc[v] = bc[v] + S;
+    }
+};
 
 __global__ void fill_f32_kernel(float* __restrict__ p, int64_t n, float v, int64_t one_at, float one_v) {
     int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -1170,6 +1269,10 @@ extern "C" int gmx_bc(gmx_graph_t* g, const gmx_node_t* seeds, int32_t nseeds, i
     if (!g->bfs_cache) GMX_CHECK(gmx_bfs_create(g, 0, 1, &g->bfs_cache));
     gmx_bfs* b = g->bfs_cache;
     dbuf<float> sigma, delta, bc;
+    dbuf<int32_t> big_list;
+    dbuf<unsigned int> big_count;
+    GMX_CHECK(big_list.alloc((size_t) V));
+    GMX_CHECK(big_count.alloc(1));
     GMX_CHECK(sigma.alloc((size_t) V));
     GMX_CHECK(delta.alloc((size_t) V));
     GMX_CHECK(bc.alloc((size_t) V));
@@ -1187,19 +1290,7 @@ extern "C" int gmx_bc(gmx_graph_t* g, const gmx_node_t* seeds, int32_t nseeds, i
         GMX_CHECK(bfs_make_order(b, &ord));
         reached += ord.h_off[(size_t) ord.levels];
         const int32_t skip = skip_root ? s : -1;
-        for (int32_t l = 0; l < ord.levels; l++) {
-            const int64_t lo = ord.h_off[(size_t) l], hi = ord.h_off[(size_t) l + 1];
-            if (hi > lo)
-                hipLaunchKernelGGL(bc_forward_kernel, dim3(grid_for(hi - lo)), dim3(BFS_THREADS), 0, 0, (const int32_t*) ord.order.p, lo, hi, l,
-                                   (const int32_t*) b->dist.p, g->r_begin.p, g->r_node_idx.p, skip, sigma.p);
-        }
-        for (int32_t l = ord.levels - 1; l >= 0; l--) {
-            const int64_t lo = ord.h_off[(size_t) l], hi = ord.h_off[(size_t) l + 1];
-            if (hi > lo)
-                hipLaunchKernelGGL(bc_reverse_kernel, dim3(grid_for(hi - lo)), dim3(BFS_THREADS), 0, 0, (const int32_t*) ord.order.p, lo, hi, l,
-                                   (const int32_t*) b->dist.p, g->begin.p, g->node_idx.p, skip, (const float*) sigma.p, delta.p, bc.p);
-        }
-        GMX_HIP(hipGetLastError());
+        GMX_CHECK(bfs_sweep(g, b, ord, skip, bc_visit_fw{sigma.p}, bc_visit_rv{sigma.p, delta.p, bc.p}, big_list.p, big_count.p));
     }
     GMX_HIP(hipEventRecord(e1.e, 0));
     GMX_HIP(hipEventSynchronize(e1.e));
