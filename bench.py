@@ -109,17 +109,27 @@ def extras(gmx, graph26, scale):
     g24.free()
     T, st = gs.triangle_counting()
     T2, st2 = gs.triangle_counting()            # second call: the degree-ordered copy is cached, like the reverse CSR
+    import numpy as np
+    deg = np.diff(gs.download(reverse=False)[0]).astype(np.float64)
+    merge_bytes = 4.0 * float(np.sum(deg * deg))    # sum over edges (v,u), u > v of 4 (d(v) + d(u)) = 4 sum_v d(v)^2 on a symmetric simple graph
     out["triangle_counting_rmat24_sym"] = {"seconds": st2["kernel_ms"] * 1e-3, "first_call_seconds": st["kernel_ms"] * 1e-3,
                                             "triangles": T, "edges": gs.E, "gteps": gs.E / (st2["kernel_ms"] * 1e-3) / 1e9,
-                                            "note": "BASELINE configs[4]; E = edge slots of the symmetrised graph"}
+                                            "merge_form_algorithmic_bytes": merge_bytes,
+                                            "merge_form_gbs": merge_bytes / (st2["kernel_ms"] * 1e-3) / 1e9,
+                                            "note": "BASELINE configs[4]; E = edge slots of the symmetrised graph; merge_form_* = SURVEY 8d's figure for the "
+                                                    "sorted-merge form in the emitted vertex order (4 sum d^2) over the measured time -- the degree-ordered "
+                                                    "kernel skips most of that work; its measured HBM traffic and unit utilisation: "
+                                                    "profiles/round3_tc_rmat24_pmc.txt"}
     assert T == T2
     gs.free()
     # hop_dist from vertex 0 on RMAT-26 without the final permutation (vertex 0 is then the top hub; with
     # permute=true vertex 0 may be isolated)
     gb = gmx.Graph.rmat(1 << scale, 16 << scale, 1997, 0.57, 0.19, 0.19, False)
-    runs = []
+    runs, walls = [], []
     for _ in range(4):
+        t0 = time.perf_counter()
         _, st = gb.hop_dist(0)
+        walls.append((time.perf_counter() - t0) * 1e3)
         runs.append(st)
     st = sorted(runs[1:], key=lambda r: r["kernel_ms"])[1]
     t = st["kernel_ms"] * 1e-3
@@ -127,9 +137,13 @@ def extras(gmx, graph26, scale):
         "ms": st["kernel_ms"], "levels": st["iterations"], "vertices_reached": st["vertices_reached"],
         "edges_reached": st["edges_reached"], "edges_examined": st["edges_examined"],
         "gteps": st["edges_reached"] / t / 1e9,
+        "first_call_wall_ms": walls[0], "warm_call_wall_ms": sorted(walls[1:])[1],
         "roofline_frac": (8 * st["edges_reached"] + 12 * st["vertices_reached"]) / t / 1e9 / HBM_PEAK_GBS,
-        "note": "BASELINE configs[2]; median of 3 warm traversals; TEPS in the Graph500 convention (out-edges of the reached "
-                "vertices / time); algorithmic bytes 8 E_r + 12 V_r -- direction optimisation examines fewer edges"}
+        "note": "BASELINE configs[2]; ms = median of 3 warm traversals (device time of the traversal); the wall-clock figures are whole "
+                "gmx_hop_dist calls incl. the 256 MB dist[] download, the first one also the per-graph bottom-up hint and traversal "
+                "state; TEPS in the Graph500 convention (out-edges of the reached vertices / time); algorithmic bytes 8 E_r + 12 V_r -- "
+                "direction optimisation examines fewer edges, so this fraction is a work-skipping figure, not bandwidth (measured "
+                "traffic: profiles/round3_bfs_rmat26_pmc.txt)"}
     gb.free()
     return out
 
