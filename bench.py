@@ -346,6 +346,10 @@ def main():
                        "options": options, "setup_s": round(setup_s, 2), "last_diff": last_diff},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         # the bytes the kernels really move (PMC) over the same time: the honest bandwidth figure next to
+                         # the contract's algorithmic one (the binned layout moves fewer bytes than 8E + 20V charges)
+                         "traffic_gbs": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic and kernel_ms > 0 else None,
+                         "traffic_frac": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and kernel_ms > 0 else None,
                          "copy_bw_gbs": copy_gbs, "frac_of_copy": (achieved / copy_gbs) if copy_gbs else None,
                          "kernel_code_hash": code_hash,
                          "kernel": kernel_name, "kernel_ms": kernel_ms, "launches": launches,
