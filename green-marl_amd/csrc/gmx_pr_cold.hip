@@ -1836,6 +1836,9 @@ bool pr_cold_limb_guard(const pr_cold* c, double d, double N) {
     const double base = (1.0 - d) / N, dstar = base * 0x1p39;
     int64_t risky = 0;
     for (int32_t m : c->tile_maxdeg) risky += (double) m > dstar;
+    if (getenv("GMX_PR_DEBUG"))
+        fprintf(stderr, "gmx pr cold: fp32 limb guard: %lld tiles hold a source of out-degree > %.0f, at most %.1f allowed (d = %g)\n",
+                (long long) risky, dstar, 0x1p-22 * base / (64.0 * 0x1p-62 * d), d);
     return (double) risky * 64.0 * 0x1p-62 * d <= 0x1p-22 * base;
 }
 
