@@ -12,7 +12,8 @@ gmx.require_device()
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 26
 elem = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 g = gmx.Graph.rmat(1 << scale, 16 << scale, 1997, 0.57, 0.19, 0.19, True)
-for n in (1, 2, 4, 8):
+ranks = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 4, 8]
+for n in ranks:
     t0 = time.perf_counter()
     st = gmx.PageRankState(g, elem, 0, n, gmx.default_pr_options(g.V, n))
     build = time.perf_counter() - t0
