@@ -166,6 +166,7 @@ tc_forward_only_kernel(const int32_t* __restrict__ begin, const int32_t* __restr
 #define TCO_CLAIM 8     // work items per dequeue
 #define TCO_ALONE 4     // a lane walks a side of up to this many entries by itself (measured flat from 0 to 8; 48: +25 %)
 #define TCO_RATIO 4     // stream Up(u) and search the staged tail while |Up(u)| <= TCO_RATIO * |tail| (2: +15 %, 16: +7 %)
+#define TCO_PIECES 4    // 256-byte pieces of Up(u) a wave keeps in flight
 #define TCO_CAP 1024    // upper-list entries staged per wave (4 KiB; 4 waves: 16 KiB of LDS per workgroup, 8 workgroups per CU)
 
 __global__ void tc_up_begin_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx, int64_t V,
@@ -267,10 +268,24 @@ tc_oriented_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict_
                 const int32_t sbb = __shfl(bb, src, 64), sbe = __shfl(be, src, 64);
                 const int32_t sdb = sbe - sbb, sta = da - (src + 1);
                 if (in_lds && sdb <= ratio * sta) {   // stream Up(u), search the staged tail
-                    for (int32_t p = sbb + lane; p < sbe; p += 64) {
-                        const int32_t w = node_idx[p];
-                        const int32_t f = tco_lds_lower_bound(A, src + 1, da, w);
-                        c += (f < da && A[f] == w) ? 1 : 0;
+                    // TCO_PIECES 256-byte pieces of Up(u) in flight per wave before the searches start: with one piece per
+                    // step the next load waited behind ten dependent LDS probes (282 -> 264 ms on symmetrised RMAT-24).
+                    // Measured and not kept (profiles/round3_tc_*: the kernel fetches 0.68 TB per call at 2.4 TB/s with the
+                    // VALU 10 % and the LDS 1 % busy): 8 pieces (274 ms), the next slot's first pieces requested while the
+                    // current slot is searched (266 ms), Up(v) as an LDS hash set instead of a sorted list (one or two reads
+                    // per probe, but 8 KiB per wave: 20 waves per CU instead of 32 -> 593 ms), every edge handled at the end
+                    // with the longer list (0.44 TB fetched, 308 ms).  What limits it is the rate at which the memory system
+                    // delivers these scattered 0.25-2.5 KB list reads, not the wave's own latency chain.
+                    for (int32_t p = sbb + lane; p < sbe; p += TCO_PIECES * 64) {
+                        int32_t w[TCO_PIECES];
+#pragma unroll
+                        for (int k = 0; k < TCO_PIECES; k++) w[k] = p + 64 * k < sbe ? node_idx[p + 64 * k] : -1;
+#pragma unroll
+                        for (int k = 0; k < TCO_PIECES; k++) {
+                            if (w[k] < 0) continue;
+                            const int32_t f = tco_lds_lower_bound(A, src + 1, da, w[k]);
+                            c += (f < da && A[f] == w[k]) ? 1 : 0;
+                        }
                     }
                 } else {                               // stream the tail of Up(v), search Up(u) in memory
                     for (int32_t p = src + 1 + lane; p < da; p += 64)
