@@ -83,7 +83,8 @@ void gmx_ws_rewind(gmx_ws_mark m);
 struct gmx_ws_scope {
     gmx_ws_mark m;
     gmx_ws_scope() : m(gmx_ws_top()) {}
-    ~gmx_ws_scope() { gmx_ws_rewind(m); }
+    // (nothing may still be running on memory that the next build will hand out again: also on the error paths)
+    ~gmx_ws_scope() { (void) hipDeviceSynchronize(); gmx_ws_rewind(m); }
     gmx_ws_scope(const gmx_ws_scope&) = delete;
     gmx_ws_scope& operator=(const gmx_ws_scope&) = delete;
 };
