@@ -175,6 +175,76 @@ class PipelinedFileEngine(SharedFileEngine):
             self.contrib[cur] = live
 
 
+class PackedFileEngine(PipelinedFileEngine):
+    """The packed push ("send only what is read", gmx_pr_push_packed / gmx_pr_unpack) on files: per peer the sorted
+    positions of its range this rank reads, a landing zone per replica parity that the peers write their packed pieces
+    into, and an unpack that scatters them into the replica.  The replicas start as NaN outside the owned range, so a
+    position that was needed but never sent -- or a gather that ran before its unpack -- poisons the ranks."""
+
+    def __init__(self, g, rank, world, tmp_dir):
+        super().__init__(g, rank, world, tmp_dir)
+        for c in self.contrib:
+            c[:] = float("nan")
+            c[g.N:] = 0.0            # (padding behind the last vertex: never a source)
+        sl = self.slice
+        # reads[q][r]: positions inside rank r's range that rank q reads (the sources of q's in-edges)
+        self.reads = []
+        for q in range(world):
+            qlo, qhi = q * sl, min(g.N, (q + 1) * sl)
+            src = np.unique(g.r_node_idx[(self.dst >= qlo) & (self.dst < qhi)])
+            self.reads.append([src[(src >= r * sl) & (src < (r + 1) * sl)] - r * sl for r in range(world)])
+        self.roff = np.concatenate([[0], np.cumsum([len(x) for x in self.reads[rank]])]).astype(np.int64)
+        self.lpaths = [os.path.join(tmp_dir, "landing_r%d_b%d.bin" % (rank, b)) for b in (0, 1)]
+        self.landing = [np.memmap(p, dtype=np.float64, mode="w+", shape=(max(int(self.roff[-1]), 1),)) for p in self.lpaths]
+        for m in self.landing:
+            m[:] = np.nan
+
+    def packed(self):
+        return True
+
+    def recv_list(self, r):
+        return torch.from_numpy(self.reads[self.rank][r].astype(np.int64))
+
+    def ipc_handles(self):
+        return {"replica": list(self.paths), "landing": list(self.lpaths), "size": int(self.roff[-1])}
+
+    def set_peers(self, handles):
+        self.peer_landing = [None if r == self.rank else
+                             [np.memmap(p, dtype=np.float64, mode="r+", shape=(max(h["size"], 1),)) for p in h["landing"]]
+                             for r, h in enumerate(handles)]
+        # where my segment starts in peer q's landing zone: q's recv offsets, which I can compute like q does
+        self.my_off = [int(sum(len(x) for x in self.reads[q][:self.rank])) for q in range(self.world)]
+
+    def _push(self, b, off, cnt):
+        own = self.contrib[b].numpy()[self.rank * self.slice:(self.rank + 1) * self.slice]
+        for q in range(self.world):
+            if q == self.rank:
+                continue
+            lst = self.reads[q][self.rank]
+            a, e = np.searchsorted(lst, off), np.searchsorted(lst, off + cnt)
+            self.peer_landing[q][b][self.my_off[q] + a:self.my_off[q] + e] = own[lst[a:e]]
+            self.peer_landing[q][b].flush()
+
+    def unpack(self, chunk=-1):
+        off, cnt = (0, self.slice) if chunk < 0 else self.chunk_range(chunk)
+        b = self.cur
+        dst = self.contrib[b].numpy()
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            lst = self.reads[self.rank][r]
+            a, e = np.searchsorted(lst, off), np.searchsorted(lst, off + cnt)
+            dst[r * self.slice + lst[a:e]] = self.landing[b][self.roff[r] + a:self.roff[r] + e]
+
+    def step_gather(self, cls):
+        super().step_gather(cls)
+        # (the owned range and the listed positions are the only finite entries a step may meet)
+
+    def step_chunk(self, c):
+        super().step_chunk(c)
+        assert np.isfinite(self.rank_v).all(), "a position this rank reads had not been unpacked when it was gathered"
+
+
 class BrokenPushEngine(SharedFileEngine):
     """Peer copies that silently land nowhere: DistPageRank's one-time check must notice and fall back."""
 
@@ -190,7 +260,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, scale, out_dir, chunks=1, push=False, broken=False, pipelined=False):
+def _worker(rank, world, port, scale, out_dir, chunks=1, push=False, broken=False, pipelined=False, packed=False):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (os.path.join(here, "..", "green-marl_amd"), os.path.join(here, "..", "oracle")):
@@ -200,7 +270,7 @@ def _worker(rank, world, port, scale, out_dir, chunks=1, push=False, broken=Fals
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = po.rmat_graph(scale, permute=True)
-    cls = BrokenPushEngine if broken else PipelinedFileEngine if pipelined else SharedFileEngine
+    cls = BrokenPushEngine if broken else PackedFileEngine if packed else PipelinedFileEngine if pipelined else SharedFileEngine
     eng = cls(g, rank, world, out_dir) if push else NumpyEngine(g, rank, world)
     eng.set_chunks(chunks)
     pr = DistPageRank(eng, exchange="push", barrier="host") if push else DistPageRank(eng)
@@ -219,11 +289,12 @@ def _worker(rank, world, port, scale, out_dir, chunks=1, push=False, broken=Fals
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,chunks,push,broken,pipelined", [
-    (2, 1, False, False, False), (3, 1, False, False, False), (2, 4, False, False, False), (3, 3, False, False, False),
-    (2, 1, True, False, False), (3, 2, True, False, False), (2, 2, True, True, False),
-    (2, 2, True, False, True), (3, 2, True, False, True), (2, 3, True, False, True)])
-def test_dist_pagerank_gloo(tmp_path, world, chunks, push, broken, pipelined):
+@pytest.mark.parametrize("world,chunks,push,broken,pipelined,packed", [
+    (2, 1, False, False, False, False), (3, 1, False, False, False, False), (2, 4, False, False, False, False), (3, 3, False, False, False, False),
+    (2, 1, True, False, False, False), (3, 2, True, False, False, False), (2, 2, True, True, False, False),
+    (2, 2, True, False, True, False), (3, 2, True, False, True, False), (2, 3, True, False, True, False),
+    (2, 1, True, False, True, True), (3, 2, True, False, True, True), (2, 2, True, False, True, True), (3, 3, True, False, True, True)])
+def test_dist_pagerank_gloo(tmp_path, world, chunks, push, broken, pipelined, packed):
     """chunks > 1: the sweep is enqueued in row chunks and each chunk's piece is all-gathered (async) while
     the next chunk is computed -- the overlap path the GPU ranks take for N > 1.
     push: the exchange by direct copies into the peers' replicas (files here, hipIpc-mapped HBM on the GPUs),
@@ -231,9 +302,11 @@ def test_dist_pagerank_gloo(tmp_path, world, chunks, push, broken, pipelined):
     against a collective one and every rank falls back to the all-gather.
     pipelined: an engine whose step reads the peers' contributions in two gather calls (hub pieces / the rest),
     driven in DistPageRank's pipelined order -- gather(0) right after the per-step barrier, gather(1) after the early
-    barrier of the previous step's tail chunk."""
+    barrier of the previous step's tail chunk.
+    packed: only the positions a peer reads travel, through landing zones, and are scattered by unpack() behind the
+    barriers (DistPageRank's packed order); everything else in the replicas is NaN."""
     scale = 11
-    mp.spawn(_worker, args=(world, _free_port(), scale, str(tmp_path), chunks, push, broken, pipelined), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), scale, str(tmp_path), chunks, push, broken, pipelined, packed), nprocs=world, join=True)
     g = po.rmat_graph(scale, permute=True)
     want, it, want_diff = po.pagerank(g, 0.001, 0.85, 100, nthreads=1)
     got = np.zeros(g.N)
