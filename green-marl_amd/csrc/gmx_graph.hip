@@ -796,3 +796,52 @@ extern "C" int gmx_graph_reverse_edge_map(const gmx_graph_t* g, gmx_edge_t* e_re
     GMX_HIP(hipMemcpy(e_rev2idx, val2.p, sizeof(int32_t) * (size_t) g->E, hipMemcpyDeviceToHost));
     return GMX_OK;
 }
+
+// ------------------------------------------------------------------ GM_EDGE64 host builds (include/gmx.h)
+// edge_t = int64_t on the host, 32-bit edge offsets on the device: narrow on the way in, widen on the way out.
+extern "C" int gmx_graph_upload_e64(const int64_t* begin, const gmx_node_t* node_idx, const int64_t* r_begin, const gmx_node_t* r_node_idx,
+                                    int64_t V, int64_t E, uint32_t flags, gmx_graph_t** out) {
+    GMX_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    GMX_REQUIRE(V >= 0 && E >= 0 && (begin || V == 0), "bad argument");
+    GMX_REQUIRE(E < (1LL << 31) - (1LL << 27), "%lld edges: the device kernels keep 32-bit edge offsets (below 2^31 - 2^27 edges)", (long long) E);
+    std::vector<int32_t> b32((size_t) V + 1, 0), rb32;
+    for (int64_t i = 0; i <= V && begin; i++) {
+        GMX_REQUIRE(begin[i] >= 0 && begin[i] <= E, "begin[%lld] = %lld outside [0, E]", (long long) i, (long long) begin[i]);
+        b32[(size_t) i] = (int32_t) begin[i];
+    }
+    if (r_begin) {
+        rb32.resize((size_t) V + 1);
+        for (int64_t i = 0; i <= V; i++) {
+            GMX_REQUIRE(r_begin[i] >= 0 && r_begin[i] <= E, "r_begin[%lld] = %lld outside [0, E]", (long long) i, (long long) r_begin[i]);
+            rb32[(size_t) i] = (int32_t) r_begin[i];
+        }
+    }
+    return gmx_graph_upload(b32.data(), node_idx, r_begin ? rb32.data() : nullptr, r_node_idx, V, E, flags, out);
+}
+
+extern "C" int gmx_graph_download_e64(const gmx_graph_t* g, int64_t* begin, gmx_node_t* node_idx, int64_t* r_begin, gmx_node_t* r_node_idx) {
+    GMX_REQUIRE(g, "graph is NULL");
+    std::vector<int32_t> b32(begin ? (size_t) g->V + 1 : 0), rb32(r_begin ? (size_t) g->V + 1 : 0);
+    GMX_CHECK(gmx_graph_download(g, begin ? b32.data() : nullptr, node_idx, r_begin ? rb32.data() : nullptr, r_node_idx));
+    for (size_t i = 0; i < b32.size(); i++) begin[i] = b32[i];
+    for (size_t i = 0; i < rb32.size(); i++) r_begin[i] = rb32[i];
+    return GMX_OK;
+}
+
+extern "C" int gmx_graph_edge_order_e64(const gmx_graph_t* g, int64_t* e_idx2idx, int* is_identity) {
+    GMX_REQUIRE(g && e_idx2idx && is_identity, "NULL argument");
+    std::vector<int32_t> m((size_t) g->E);
+    GMX_CHECK(gmx_graph_edge_order(g, m.data(), is_identity));
+    if (!*is_identity)
+        for (size_t i = 0; i < m.size(); i++) e_idx2idx[i] = m[i];
+    return GMX_OK;
+}
+
+extern "C" int gmx_graph_reverse_edge_map_e64(const gmx_graph_t* g, int64_t* e_rev2idx) {
+    GMX_REQUIRE(g && e_rev2idx, "NULL argument");
+    std::vector<int32_t> m((size_t) g->E);
+    GMX_CHECK(gmx_graph_reverse_edge_map(g, m.data()));
+    for (size_t i = 0; i < m.size(); i++) e_rev2idx[i] = m[i];
+    return GMX_OK;
+}

@@ -12,6 +12,14 @@
 
 #include "gmx.h"
 
+// edge offsets cross the C ABI as edge_t: a GM_EDGE64 build of this library uses the 64-bit variants of the graph calls
+#ifdef GM_EDGE64
+#define gmx_graph_upload gmx_graph_upload_e64
+#define gmx_graph_download gmx_graph_download_e64
+#define gmx_graph_edge_order gmx_graph_edge_order_e64
+#define gmx_graph_reverse_edge_map gmx_graph_reverse_edge_map_e64
+#endif
+
 int GM_SIZE_CHECK_VAR;
 
 gm_graph::gm_graph()

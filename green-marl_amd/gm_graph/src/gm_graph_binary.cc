@@ -1,6 +1,7 @@
 // gm_graph_binary.cc -- the custom binary graph format.
 // Format (all big-endian; /root/reference/apps/output_cpp/gm_graph/src/gm_graph_binary_loader.cc:19-26):
 //   magic 0x03939999 | sizeof(node_t) | sizeof(edge_t) | N | M | begin[N+1] | node_idx[M]
+// (N, node_idx: node_t-sized fields; M, begin: edge_t-sized fields -- 8 bytes in a GM_EDGE64 build)
 // A byte-flipped legacy variant (magic readable without swapping) is accepted too (:68-87).
 // Like the reference (:191-197) a loaded graph is semi-sorted and gets its reverse edges.
 // The reference reads element by element; this reader pulls each array with one fread and swaps in parallel.
@@ -14,6 +15,14 @@
 
 #include "gm_graph.h"
 #include "gmx.h"
+
+// edge offsets cross the C ABI as edge_t: a GM_EDGE64 build of this library uses the 64-bit variants of the graph calls
+#ifdef GM_EDGE64
+#define gmx_graph_upload gmx_graph_upload_e64
+#define gmx_graph_download gmx_graph_download_e64
+#define gmx_graph_edge_order gmx_graph_edge_order_e64
+#define gmx_graph_reverse_edge_map gmx_graph_reverse_edge_map_e64
+#endif
 
 // GMX_LOAD_TIMING=1: where load_binary spends its time (stderr)
 static double load_now_ms() {
@@ -33,6 +42,30 @@ static bool read_u32_array(FILE* f, int32_t* dst, size_t n, bool swap) {
     if (swap) {
 #pragma omp parallel for
         for (size_t i = 0; i < n; i++) dst[i] = (int32_t) ntohl((uint32_t) dst[i]);
+    }
+    return true;
+}
+
+static inline uint64_t swap_u64(uint64_t v) { return ((uint64_t) ntohl((uint32_t) v) << 32) | ntohl((uint32_t) (v >> 32)); }
+
+// n edge-typed fields of `esz` bytes each (4 or 8; a library built with a wider edge_t reads the narrower files too,
+// like the reference's BITS_TO_EDGE, gm_graph_binary_loader.cc:118-126)
+static bool read_edge_array(FILE* f, edge_t* dst, size_t n, uint32_t esz, bool swap) {
+    if (esz == 4 && sizeof(edge_t) == 4) return read_u32_array(f, (int32_t*) dst, n, swap);
+    if (esz == 4) {   // widen in place, back to front
+        if (n && fread(dst, 4, n, f) != n) return false;
+        const int32_t* narrow = (const int32_t*) dst;
+        for (size_t i = n; i-- > 0;) {
+            const int32_t v = narrow[i];
+            dst[i] = (edge_t) (swap ? (int32_t) ntohl((uint32_t) v) : v);
+        }
+        return true;
+    }
+    if (sizeof(edge_t) != 8) return false;
+    if (n && fread(dst, 8, n, f) != n) return false;
+    if (swap) {
+#pragma omp parallel for
+        for (size_t i = 0; i < n; i++) dst[i] = (edge_t) swap_u64((uint64_t) dst[i]);
     }
     return true;
 }
@@ -60,21 +93,23 @@ bool gm_graph::load_binary(char* filename) {
     if (ok) {
         nsz = swap ? ntohl(hdr[1]) : hdr[1];
         esz = swap ? ntohl(hdr[2]) : hdr[2];
-        if (nsz != sizeof(node_t) || esz != sizeof(edge_t)) {
+        // (the reference accepts files whose fields are narrower than the library's types, :93-101)
+        if (nsz != sizeof(node_t) || (esz != 4 && esz != 8) || esz > sizeof(edge_t)) {
             fprintf(stderr, "node_t/edge_t size mismatch: file has %u/%u bytes, library expects %zu/%zu; please re-generate the graph\n",
                     nsz, esz, sizeof(node_t), sizeof(edge_t));
             ok = false;
         }
     }
-    int32_t nm[2] = {0, 0};
-    if (ok) ok = read_u32_array(f, nm, 2, swap);
-    if (ok && (nm[0] < 0 || nm[1] < 0)) ok = false;
+    int32_t n_file = 0;
+    edge_t m_file = 0;
+    if (ok) ok = read_u32_array(f, &n_file, 1, swap) && read_edge_array(f, &m_file, 1, esz, swap);
+    if (ok && (n_file < 0 || m_file < 0)) ok = false;
     if (ok) {
-        printf("N = %ld, M = %ld\n", (long) nm[0], (long) nm[1]);
-        prepare_external_creation(nm[0], nm[1]);
-        ok = read_u32_array(f, begin, (size_t) nm[0] + 1, swap) && read_u32_array(f, node_idx, (size_t) nm[1], swap);
+        printf("N = %ld, M = %ld\n", (long) n_file, (long) m_file);
+        prepare_external_creation(n_file, m_file);
+        ok = read_edge_array(f, begin, (size_t) n_file + 1, esz, swap) && read_u32_array(f, node_idx, (size_t) m_file, swap);
         if (!ok) fprintf(stderr, "Error reading the CSR arrays\n");
-        else if (begin[0] != 0 || begin[nm[0]] != nm[1]) {
+        else if (begin[0] != 0 || begin[n_file] != m_file) {
             fprintf(stderr, "corrupt file: begin[] does not cover the edge array\n");
             ok = false;
         }
@@ -167,19 +202,31 @@ bool gm_graph::store_binary(char* filename) {
         return false;
     }
     const size_t N = (size_t) _numNodes, M = (size_t) _numEdges;
-    uint32_t hdr[5] = {htonl(MAGIC_WORD_BIN), htonl((uint32_t) sizeof(node_t)), htonl((uint32_t) sizeof(edge_t)),
-                       htonl((uint32_t) _numNodes), htonl((uint32_t) _numEdges)};
-    bool ok = fwrite(hdr, 4, 5, f) == 5;
+    uint32_t hdr[4] = {htonl(MAGIC_WORD_BIN), htonl((uint32_t) sizeof(node_t)), htonl((uint32_t) sizeof(edge_t)), htonl((uint32_t) _numNodes)};
+    bool ok = fwrite(hdr, 4, 4, f) == 4;
     const size_t chunk = 1 << 20;
-    uint32_t* buf = new uint32_t[chunk];
-    for (int pass = 0; pass < 2 && ok; pass++) {
-        const int32_t* src = pass == 0 ? begin : node_idx;
-        const size_t n = pass == 0 ? N + 1 : M;
+    uint64_t* buf = new uint64_t[chunk];
+    // an edge-typed field: sizeof(edge_t) bytes, big-endian (gm_graph_binary_loader.cc:238-244)
+    auto put_edges = [&](const edge_t* src, size_t n) {
         for (size_t off = 0; off < n && ok; off += chunk) {
             const size_t c = n - off < chunk ? n - off : chunk;
-            for (size_t i = 0; i < c; i++) buf[i] = htonl((uint32_t) src[off + i]);
-            ok = fwrite(buf, 4, c, f) == c;
+            if (sizeof(edge_t) == 4) {
+                uint32_t* b32 = (uint32_t*) buf;
+                for (size_t i = 0; i < c; i++) b32[i] = htonl((uint32_t) src[off + i]);
+            } else {
+                for (size_t i = 0; i < c; i++) buf[i] = swap_u64((uint64_t) src[off + i]);
+            }
+            ok = fwrite(buf, sizeof(edge_t), c, f) == c;
         }
+    };
+    const edge_t m_field = _numEdges;
+    put_edges(&m_field, 1);
+    put_edges(begin, N + 1);
+    for (size_t off = 0; off < M && ok; off += chunk) {
+        const size_t c = M - off < chunk ? M - off : chunk;
+        uint32_t* b32 = (uint32_t*) buf;
+        for (size_t i = 0; i < c; i++) b32[i] = htonl((uint32_t) node_idx[off + i]);
+        ok = fwrite(b32, 4, c, f) == c;
     }
     delete[] buf;
     fclose(f);

@@ -44,6 +44,7 @@ EXPORTS = [
     "gmx_workspace_bytes", "gmx_workspace_release", "gmx_last_error", "gmx_device_count", "gmx_set_device", "gmx_device_info", "gmx_copy_bandwidth",
     "gmx_graph_upload", "gmx_graph_from_edges", "gmx_graph_create_rmat", "gmx_graph_free", "gmx_graph_symmetrize",
     "gmx_graph_num_nodes", "gmx_graph_num_edges", "gmx_graph_download", "gmx_graph_edge_order",
+    "gmx_graph_upload_e64", "gmx_graph_download_e64", "gmx_graph_edge_order_e64", "gmx_graph_reverse_edge_map_e64",
     "gmx_pagerank_f64", "gmx_pagerank_f32", "gmx_hop_dist", "gmx_bfs_levels", "gmx_bc", "gmx_sssp", "gmx_avg_teen_cnt", "gmx_conduct", "gmx_triangle_counting", "gmx_triangle_counting_part", "gmx_triangle_counting_cn", "gmx_common_nbrs", "gmx_common_nbr_counts", "gmx_graph_reverse_edge_map",
     "gmx_bfs_create", "gmx_bfs_free", "gmx_bfs_start", "gmx_bfs_step_begin", "gmx_bfs_found_bitmap", "gmx_bfs_step_end",
     "gmx_bfs_download",
@@ -107,6 +108,10 @@ def lib():
         L.gmx_avg_teen_cnt.argtypes = [vp, vp, i32, vp, C.POINTER(C.c_float), C.POINTER(Stats)]
         L.gmx_conduct.argtypes = [vp, vp, i32, C.POINTER(C.c_float), C.POINTER(Stats)]
         L.gmx_graph_reverse_edge_map.argtypes = [vp, vp]
+        L.gmx_graph_upload_e64.argtypes = [vp, vp, vp, vp, i64, i64, C.c_uint32, C.POINTER(vp)]
+        L.gmx_graph_download_e64.argtypes = [vp, vp, vp, vp, vp]
+        L.gmx_graph_edge_order_e64.argtypes = [vp, vp, C.POINTER(C.c_int)]
+        L.gmx_graph_reverse_edge_map_e64.argtypes = [vp, vp]
         L.gmx_triangle_counting_part.argtypes = [vp, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(Stats)]
         L.gmx_bfs_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
         L.gmx_bfs_free.argtypes = [vp]

@@ -98,6 +98,13 @@ int gmx_graph_create_rmat(int64_t N, int64_t M, long seed, double a, double b, d
 /* Undirected simple version of g (both orientations, no duplicates, no self loops); the result is
  * its own transpose.  Measurement preparation of the triangle-counting config. */
 int gmx_graph_symmetrize(const gmx_graph_t* g, gmx_graph_t** out);
+/* The same calls for a host side built with GM_EDGE64 (edge_t = int64_t, gm_graph_typedef.h:8-20): edge offsets and edge
+ * maps as int64 arrays.  The device keeps 32-bit edge offsets: E must be below 2^31 - 2^27 (GMX_ERR_ARG otherwise). */
+int gmx_graph_upload_e64(const int64_t* begin, const gmx_node_t* node_idx, const int64_t* r_begin, const gmx_node_t* r_node_idx,
+                         int64_t V, int64_t E, uint32_t flags, gmx_graph_t** out);
+int gmx_graph_download_e64(const gmx_graph_t* g, int64_t* begin, gmx_node_t* node_idx, int64_t* r_begin, gmx_node_t* r_node_idx);
+int gmx_graph_edge_order_e64(const gmx_graph_t* g, int64_t* e_idx2idx, int* is_identity);
+int gmx_graph_reverse_edge_map_e64(const gmx_graph_t* g, int64_t* e_rev2idx);
 int gmx_graph_free(gmx_graph_t* g);
 int64_t gmx_graph_num_nodes(const gmx_graph_t* g);
 int64_t gmx_graph_num_edges(const gmx_graph_t* g);

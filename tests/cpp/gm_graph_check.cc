@@ -6,9 +6,10 @@
 #include <stdlib.h>
 #include "gm.h"
 
-static void dump(FILE* f, const char* name, const int32_t* a, long n) {
+template <typename T>   // (edge_t arrays are int64 in a GM_EDGE64 build)
+static void dump(FILE* f, const char* name, const T* a, long n) {
     fprintf(f, "%s", name);
-    for (long i = 0; i < n; i++) fprintf(f, " %d", a[i]);
+    for (long i = 0; i < n; i++) fprintf(f, " %lld", (long long) a[i]);
     fprintf(f, "\n");
 }
 

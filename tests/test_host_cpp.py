@@ -267,3 +267,110 @@ def test_gm_graph_api_with_device(host_built, golden, tmp_path):
 def test_gmx_bench_tool(host_built):
     r = subprocess.run([os.path.join(PKG, "bin", "gmx_bench")], stdout=subprocess.PIPE, text=True)
     assert r.returncode == 0 and "gfx950" in r.stdout
+
+
+# ---------------------------------------------------------------- GM_EDGE64 host build (edge_t = int64_t)
+LINK64 = [os.path.join(PKG, "libgmgraph_e64.a")] + LINK[1:]
+
+
+@pytest.fixture(scope="module")
+def host64_built(host_built):
+    subprocess.check_call(["make", "-C", PKG, "-j4", "host64"], stdout=subprocess.DEVNULL)
+    return PKG
+
+
+def _e64_file(host64_built, golden, tmp_path):
+    """gm_graph_check built with -DGM_EDGE64: loads the committed 32-bit file (a wider library reads the narrower file,
+    gm_graph_binary_loader.cc:93-101) and stores it with 8-byte edge fields."""
+    exe = str(tmp_path / "gm_graph_check64")
+    subprocess.check_call(["g++"] + CXX_FLAGS + ["-DGM_EDGE64", os.path.join(ROOT, "tests", "cpp", "gm_graph_check.cc"), "-o", exe] + LINK64)
+    src = os.path.join(GOLD, golden["manifest"]["bin"]["file"])
+    out_bin, dump = str(tmp_path / "o64.bin"), str(tmp_path / "d64.txt")
+    r = subprocess.run([exe, src, out_bin, dump], stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout)
+    return exe, out_bin, parse_dump(dump)
+
+
+def test_edge64_host_build(host64_built, golden, tmp_path):
+    """The host side built for edge_t = int64_t (the reference's EDGE_SIZE=64, common.mk:46-52): same API results as the
+    32-bit build, the .bin format with 8-byte edge fields (gm_graph_binary_loader.cc:19-26, :222-252), and the link-time
+    size check.  The reference itself does not compile in this configuration (gm_graph.cc:226), so the 64-bit bytes are
+    checked against the documented layout, not against a reference-written file: parity unpinned for that file."""
+    exe, out_bin, d = _e64_file(host64_built, golden, tmp_path)
+    c = golden["cases"]["rmat8_noperm"]
+    for k in ("begin", "node_idx", "r_begin", "r_node_idx"):
+        assert np.array_equal(d[k], c[k]), k
+    raw = open(out_bin, "rb").read()
+    N, M = 256, 4096
+    assert len(raw) == 12 + 4 + 8 + 8 * (N + 1) + 4 * M
+    assert np.frombuffer(raw, ">u4", 4).tolist() == [0x03939999, 4, 8, N]
+    assert np.frombuffer(raw, ">i8", 1, 16)[0] == M
+    assert np.array_equal(np.frombuffer(raw, ">i8", N + 1, 24), c["begin"])
+    assert np.array_equal(np.frombuffer(raw, ">i4", M, 24 + 8 * (N + 1)), c["node_idx"])
+    # the 64-bit library reads its own file back (same arrays, same bytes out) ...
+    out2, dump2 = str(tmp_path / "o64b.bin"), str(tmp_path / "d64b.txt")
+    r = subprocess.run([exe, out_bin, out2, dump2], stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and "N = 256, M = 4096" in r.stdout, (r.returncode, r.stdout)
+    assert open(out2, "rb").read() == raw
+    assert np.array_equal(parse_dump(dump2)["r_node_idx"], c["r_node_idx"])
+    # ... and the 32-bit library refuses it, like the reference (:97-100)
+    exe32 = str(tmp_path / "gm_graph_check32")
+    subprocess.check_call(["g++"] + CXX_FLAGS + [os.path.join(ROOT, "tests", "cpp", "gm_graph_check.cc"), "-o", exe32] + LINK)
+    r = subprocess.run([exe32, out_bin, str(tmp_path / "x.bin"), str(tmp_path / "x.txt")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 1 and "size mismatch" in r.stdout
+    # an application built for 32-bit edges does not link against the 64-bit library (gm_graph_typedef.h size check)
+    r = subprocess.run(["g++"] + CXX_FLAGS + [os.path.join(ROOT, "tests", "cpp", "gm_graph_check.cc"), "-o", str(tmp_path / "bad")] + LINK64,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode != 0 and "node32_edge32" in r.stdout
+
+
+@pytest.mark.gpu
+def test_edge64_drivers_on_device(host64_built, golden, tmp_path):
+    """bin64/* (the drivers and generated entries compiled with -DGM_EDGE64) on the 64-bit file: the device mirror goes
+    through gmx_graph_upload_e64, load_binary's device preparation through the other *_e64 calls; same output lines as
+    the 32-bit build on the 32-bit file."""
+    _, out_bin, d = _e64_file(host64_built, golden, tmp_path)
+    c = golden["cases"]["rmat8_noperm"]
+    assert np.array_equal(d["r_begin"], c["r_begin"]) and np.array_equal(d["r_node_idx"], c["r_node_idx"])
+    src32 = os.path.join(GOLD, golden["manifest"]["bin"]["file"])
+    keep = re.compile(r"^(rank\[|dist\[|number of triangles|N = )")
+    for app in ("pagerank", "hop_dist", "triangle_counting"):
+        outs = []
+        for exe, f in ((os.path.join(PKG, "bin64", app), out_bin), (os.path.join(PKG, "bin", app), src32)):
+            r = subprocess.run([exe, f, "4", "/dev/null"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:]
+            outs.append([l for l in r.stdout.splitlines() if keep.match(l)])
+        assert outs[0] == outs[1] and len(outs[0]) >= 2, (app, outs)
+
+
+@pytest.mark.gpu
+def test_edge64_capi_limits_and_round_trip(golden):
+    """gmx_graph_upload_e64 / download_e64 / edge_order_e64 / reverse_edge_map_e64 against the 32-bit calls; refusals."""
+    import ctypes as C
+    sys.path.insert(0, PKG)
+    import gmx
+    L = gmx.lib()
+    c = golden["cases"]["rmat8_noperm"]
+    N, M = 256, 4096
+    b64 = np.ascontiguousarray(c["begin"], np.int64)
+    idx = np.ascontiguousarray(c["node_idx"], np.int32)
+    h = C.c_void_p()
+    assert L.gmx_graph_upload_e64(b64.ctypes.data, idx.ctypes.data, None, None, N, M, 0, C.byref(h)) == 0
+    ob, orb = np.zeros(N + 1, np.int64), np.zeros(N + 1, np.int64)
+    oi, ori = np.zeros(M, np.int32), np.zeros(M, np.int32)
+    assert L.gmx_graph_download_e64(h, ob.ctypes.data, oi.ctypes.data, orb.ctypes.data, ori.ctypes.data) == 0
+    assert np.array_equal(ob, c["begin"]) and np.array_equal(oi, c["node_idx"])
+    assert np.array_equal(orb, c["r_begin"]) and np.array_equal(ori, c["r_node_idx"])
+    m64, m32 = np.zeros(M, np.int64), np.zeros(M, np.int32)
+    assert L.gmx_graph_reverse_edge_map_e64(h, m64.ctypes.data) == 0 and L.gmx_graph_reverse_edge_map(h, m32.ctypes.data) == 0
+    assert np.array_equal(m64, m32)
+    ident = C.c_int(0)
+    assert L.gmx_graph_edge_order_e64(h, m64.ctypes.data, C.byref(ident)) == 0 and ident.value == 1
+    L.gmx_graph_free(h)
+    # refusals: an edge count the 32-bit device offsets cannot hold; offsets outside [0, E]
+    h2 = C.c_void_p()
+    assert L.gmx_graph_upload_e64(b64.ctypes.data, idx.ctypes.data, None, None, N, 1 << 31, 0, C.byref(h2)) != 0 and not h2.value
+    assert b"32-bit edge offsets" in L.gmx_last_error()
+    bad = b64.copy()
+    bad[5] = 1 << 40
+    assert L.gmx_graph_upload_e64(bad.ctypes.data, idx.ctypes.data, None, None, N, M, 0, C.byref(h2)) != 0 and not h2.value
