@@ -404,7 +404,8 @@ struct gmx_bfs {
 };
 
 // The in-neighbour a bottom-up level tries first: of the first BFS_HINT_SCAN entries of the in-row the one with most
-// out-edges -- the vertex most likely to be in a frontier early.  A hit settles the vertex from 8 bytes (dist, hint)
+// out-edges -- the vertex most likely to be in a frontier early (offline on RMAT-22: 98.6 % of the vertices a bottom-up
+// level finds are found through it; a second hint would add 1.2 %).  A hit settles the vertex from 8 bytes (dist, hint)
 // without touching its row; at RMAT-26 the first bottom-up level otherwise streams the whole reverse CSR (4.3 GB)
 // because every unvisited vertex reads at least the first line of its row.
 #define BFS_HINT_SCAN 32
@@ -424,12 +425,45 @@ __global__ void bfs_hint_kernel(const int32_t* __restrict__ begin, const int32_t
                 best = w;
             }
         }
-        hint[v] = best;
+        // A vertex with ONE in-edge has nothing else to look at when the hint misses: it is stored as -2 - w, and the
+        // bottom-up level then skips the row (r_begin[], the row's line, a second probe of the same bit).  RMAT-26 from
+        // vertex 0: 76 % of the vertices the first bottom-up level leaves without a parent have in-degree 1 (they are the
+        // ones found late, or never), 99.5 % in the later levels -- and a failed walk has no early exit.
+        hint[v] = e - b == 1 ? -2 - best : best;
     }
 }
 
 #define BFS_BU_OWN 32   // in-row entries a vertex checks alone before its wave helps
-// owned vertices [v_lo, v_hi), v_lo a multiple of 64: one found word per wave, no atomics
+// bit i of the low 16 bits -> bit 4 i
+__device__ __forceinline__ unsigned long long bfs_spread4(unsigned long long x) {
+    x = (x | (x << 24)) & 0x000000FF000000FFull;
+    x = (x | (x << 12)) & 0x000F000F000F000Full;
+    x = (x | (x << 6)) & 0x0303030303030303ull;
+    x = (x | (x << 3)) & 0x1111111111111111ull;
+    return x;
+}
+// lane l of a wave holds a bit for each of the vertices 4 l .. 4 l + 3 of 256; bal[j] = __ballot(bit j): the 64-bit word
+// of the vertices 64 k .. 64 k + 63
+__device__ __forceinline__ unsigned long long bfs_word_of(const unsigned long long bal[4], int k) {
+    unsigned long long w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) w |= bfs_spread4((bal[j] >> (16 * k)) & 0xFFFFull) << j;
+    return w;
+}
+
+// owned vertices [v_lo, v_hi), both multiples of 64: whole found words, no atomics
+//
+// Who still looks for a parent: in the first bottom-up level of a run every vertex with dist == INT_MAX; the level
+// leaves the ones that found none AND have in-edges as a bitmap (cand), and the following levels read that -- 8 bytes
+// per 64 vertices instead of their dist[] entries.
+//
+// A wave step takes 256 consecutive vertices, FOUR PER LANE: dist[] and hint[] arrive as one 16-byte load per lane, and
+// a lane's four hint probes are in flight together.  With one vertex per lane (rounds 2-3) the level ran at the depth of
+// the L1 miss queues (47 of ~64 line requests in flight per CU all the time, `profiles/round3_bfs_*_mempipe_pmc.txt`),
+// and a 4-byte-per-lane load is a 64-byte request where a 16-byte-per-lane load is a 128-byte one: streaming dist[] and
+// hint[] alone (536 MB at RMAT-26) took 238 us.  The vertices whose hint missed and that have more than one in-edge
+// then walk their rows -- compacted first (their offsets go through LDS), so that the walk runs with full waves
+// instead of once per vertex slot with a quarter of the lanes.
 __global__ void __launch_bounds__(BFS_THREADS)
 bfs_bottomup_part_kernel(const int32_t* __restrict__ r_begin, const int32_t* __restrict__ r_node_idx,
                          int64_t v_lo, int64_t v_hi, int64_t V, const uint32_t* __restrict__ frontier_bm,
@@ -437,94 +471,164 @@ bfs_bottomup_part_kernel(const int32_t* __restrict__ r_begin, const int32_t* __r
                          int32_t* dist_w /* NULL or == dist */, int32_t next_level, bfs_counters* __restrict__ ctr,
                          const unsigned long long* cand_in /* NULL: take the unvisited from dist[] */,
                          unsigned long long* cand_out, const int32_t* __restrict__ hint) {
-    int64_t t = v_lo + (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    __shared__ uint8_t s_walk[BFS_THREADS / 64][256];     // offsets (0..255) of the wave step's vertices that walk their row
+    __shared__ uint32_t s_wfound[BFS_THREADS / 64][8];    // ... and which of them found a parent
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t nwaves = (int64_t) gridDim.x * (BFS_THREADS / 64);
+    const int64_t word_hi = v_hi >> 6;
     unsigned long long inspected = 0, found_cnt = 0;
-    const int lane = threadIdx.x & 63;
-    for (; t < v_hi; t += stride) {   // v_hi - v_lo is a multiple of 64: whole waves
-        // A vertex looks for a parent among the first BFS_BU_OWN entries of its in-row by itself (most rows are
-        // shorter, and most long ones find a parent at once); what is left of the long rows is then searched by the
-        // whole wave, one row at a time, 64 entries per step with an early exit -- a lone lane walking a
-        // 10^4-entry row of a vertex that has no parent in this level was the tail of the whole level.
-        // Who still looks for a parent: in the first bottom-up level of a run every vertex with dist == INT_MAX; the
-        // level leaves the ones that found none AND have in-edges as a bitmap (cand), and the following levels read
-        // that -- 8 bytes per 64 vertices instead of their dist[] and r_begin[] entries (RMAT-26: two thirds of the
-        // vertices are out after the first level, and a pass over both arrays is 0.1 ms).
-        bool active;
+    for (int64_t w0 = (v_lo >> 6) + 4 * ((int64_t) blockIdx.x * (BFS_THREADS / 64) + wv); w0 < word_hi; w0 += 4 * nwaves) {
+        const int nw = word_hi - w0 < 4 ? (int) (word_hi - w0) : 4;   // words of this step (wave-uniform)
+        const int64_t v = w0 * 64 + 4 * lane;                         // this lane's vertices: v .. v + 3
+        const bool lane_in = (lane >> 4) < nw;
+        bool active[4];
+        int32_t d4[4] = {0, 0, 0, 0};
         if (cand_in) {
-            const unsigned long long cw = cand_in[t >> 6];
-            if (cw == 0ull) {   // (wave-uniform)
-                if (lane == 0) found_bm[t >> 6] = 0ull;
+            const unsigned long long cw = lane_in ? cand_in[w0 + (lane >> 4)] : 0ull;
+            const unsigned nib = (unsigned) (cw >> (4 * (lane & 15))) & 15u;
+            if (__ballot(nib != 0u) == 0ull) {   // nobody here looks for a parent
+                if (lane < nw) found_bm[w0 + lane] = 0ull;
                 continue;
             }
-            active = (cw >> lane) & 1ull;
-        } else active = t < V && dist[t] == INT_MAX;
-        bool found = false, has_in = false;
-        int32_t rest_b = 0, rest_e = 0;
-        const int32_t h = active ? hint[t] : -1;   // -1: no in-edges at all
-        if (h >= 0) {
-            has_in = true;
-            inspected++;
-            found = (frontier_bm[h >> 5] & (1u << (h & 31))) != 0;
-        }
-        if (h >= 0 && !found) {
-            const int32_t b = r_begin[t], e = r_begin[t + 1];
-            const int32_t own_e = e - b > BFS_BU_OWN ? b + BFS_BU_OWN : e;
-            // four entries and their four bitmap probes per step, all in flight together: with one entry per step the
-            // lane's walk was a chain of dependent loads (entry -> bitmap word -> branch), i.e. latency times the row
-            // length; the first hit still ends the walk and only the entries up to it count as inspected
-            // (RMAT-26 from vertex 0: 1.38 -> 1.31 ms.  Running four 64-vertex blocks per wave side by side as well was
-            // measured and bought nothing: the level is not bound by the length of one wave's load chain.)
-            for (int32_t i = b; i < own_e && !found; i += 4) {
-                const int32_t last = own_e - 1;
-                const int32_t w0 = r_node_idx[i], w1 = r_node_idx[i + 1 < last ? i + 1 : last], w2 = r_node_idx[i + 2 < last ? i + 2 : last],
-                              w3 = r_node_idx[i + 3 < last ? i + 3 : last];
-                const uint32_t p0 = frontier_bm[w0 >> 5], p1 = frontier_bm[w1 >> 5], p2 = frontier_bm[w2 >> 5], p3 = frontier_bm[w3 >> 5];
-                const int n = own_e - i < 4 ? own_e - i : 4;
-                const bool h0 = (p0 >> (w0 & 31)) & 1u, h1 = n > 1 && ((p1 >> (w1 & 31)) & 1u), h2 = n > 2 && ((p2 >> (w2 & 31)) & 1u),
-                           h3 = n > 3 && ((p3 >> (w3 & 31)) & 1u);
-                found = h0 || h1 || h2 || h3;
-                inspected += h0 ? 1 : h1 ? 2 : h2 ? 3 : h3 ? 4 : n;
+#pragma unroll
+            for (int j = 0; j < 4; j++) active[j] = (nib >> j) & 1u;
+        } else {
+            if (lane_in && v + 3 < V) {
+                const int4 q = *reinterpret_cast<const int4*>(dist + v);
+                d4[0] = q.x; d4[1] = q.y; d4[2] = q.z; d4[3] = q.w;
+            } else if (lane_in) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) d4[j] = v + j < V ? dist[v + j] : 0;
             }
-            if (!found && own_e < e) {
-                rest_b = own_e;
-                rest_e = e;
+#pragma unroll
+            for (int j = 0; j < 4; j++) active[j] = d4[j] == INT_MAX;
+        }
+        int32_t h[4] = {-1, -1, -1, -1};   // -1: not looking, or no in-edges at all
+        if (active[0] || active[1] || active[2] || active[3]) {
+            if (v + 3 < V) {
+                const int4 q = *reinterpret_cast<const int4*>(hint + v);
+                h[0] = q.x; h[1] = q.y; h[2] = q.z; h[3] = q.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) h[j] = v + j < V ? hint[v + j] : -1;
             }
         }
-        unsigned long long pending = __ballot(rest_e > rest_b);
-        while (pending) {
-            const int src = __ffsll((long long) pending) - 1;
-            pending &= pending - 1;
-            const int32_t rb = __shfl(rest_b, src, 64), re = __shfl(rest_e, src, 64);
-            bool hit = false;
-            for (int32_t i0 = rb; i0 < re && !hit; i0 += 64) {
-                const int32_t i = i0 + lane;
-                bool mine = false;
-                if (i < re) {
-                    const int32_t w = r_node_idx[i];
-                    inspected++;
-                    mine = (frontier_bm[w >> 5] & (1u << (w & 31))) != 0;
+        bool only[4], found[4], need[4];
+        uint32_t probe[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (!active[j]) h[j] = -1;
+            only[j] = h[j] < -1;               // -2 - w: w is the only in-neighbour
+            if (only[j]) h[j] = -2 - h[j];
+            probe[j] = frontier_bm[(h[j] >= 0 ? h[j] : 0) >> 5];   // (unconditional: four loads in flight, no branches between them)
+        }
+        bool any_need = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool has_in = h[j] >= 0;
+            found[j] = has_in && ((probe[j] >> (h[j] & 31)) & 1u);
+            inspected += has_in;
+            need[j] = has_in && !found[j] && !only[j];
+            any_need |= need[j];
+        }
+        if (__ballot(any_need) != 0ull) {
+            // the walkers of this step, compacted: one per lane, 64 at a time
+            if (lane < 8) s_wfound[wv][lane] = 0u;
+            int nwalk = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned long long m = __ballot(need[j]);
+                if (need[j]) s_walk[wv][nwalk + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t) (4 * lane + j);
+                nwalk += __popcll(m);
+            }
+            for (int base = 0; base < nwalk; base += 64) {
+                const bool mine = base + lane < nwalk;
+                const int off = mine ? s_walk[wv][base + lane] : 0;
+                const int64_t t = w0 * 64 + off;
+                bool f = false;
+                int32_t rest_b = 0, rest_e = 0;
+                if (mine) {
+                    // A vertex looks for a parent among the first BFS_BU_OWN entries of its in-row by itself (most rows are
+                    // shorter, and most long ones find a parent at once); what is left of the long rows is then searched by
+                    // the whole wave, one row at a time, 64 entries per step with an early exit -- a lone lane walking a
+                    // 10^4-entry row of a vertex that has no parent in this level was the tail of the whole level.
+                    const int32_t b = r_begin[t], e = r_begin[t + 1];
+                    const int32_t own_e = e - b > BFS_BU_OWN ? b + BFS_BU_OWN : e;
+                    // four entries and their four bitmap probes per step, all in flight together; the first hit still
+                    // ends the walk and only the entries up to it count as inspected
+                    for (int32_t i = b; i < own_e && !f; i += 4) {
+                        const int32_t last = own_e - 1;
+                        const int32_t w0e = r_node_idx[i], w1 = r_node_idx[i + 1 < last ? i + 1 : last], w2 = r_node_idx[i + 2 < last ? i + 2 : last],
+                                      w3 = r_node_idx[i + 3 < last ? i + 3 : last];
+                        const uint32_t p0 = frontier_bm[w0e >> 5], p1 = frontier_bm[w1 >> 5], p2 = frontier_bm[w2 >> 5], p3 = frontier_bm[w3 >> 5];
+                        const int n = own_e - i < 4 ? own_e - i : 4;
+                        const bool h0 = (p0 >> (w0e & 31)) & 1u, h1 = n > 1 && ((p1 >> (w1 & 31)) & 1u), h2 = n > 2 && ((p2 >> (w2 & 31)) & 1u),
+                                   h3 = n > 3 && ((p3 >> (w3 & 31)) & 1u);
+                        f = h0 || h1 || h2 || h3;
+                        inspected += h0 ? 1 : h1 ? 2 : h2 ? 3 : h3 ? 4 : n;
+                    }
+                    if (!f && own_e < e) {
+                        rest_b = own_e;
+                        rest_e = e;
+                    }
                 }
-                hit = __ballot(mine) != 0ull;
+                unsigned long long pending = __ballot(rest_e > rest_b);
+                while (pending) {
+                    const int src = __ffsll((long long) pending) - 1;
+                    pending &= pending - 1;
+                    const int32_t rb = __shfl(rest_b, src, 64), re = __shfl(rest_e, src, 64);
+                    bool hit = false;
+                    for (int32_t i0 = rb; i0 < re && !hit; i0 += 64) {
+                        const int32_t i = i0 + lane;
+                        bool here = false;
+                        if (i < re) {
+                            const int32_t w = r_node_idx[i];
+                            inspected++;
+                            here = (frontier_bm[w >> 5] & (1u << (w & 31))) != 0;
+                        }
+                        hit = __ballot(here) != 0ull;
+                    }
+                    if (lane == src) f = hit;
+                }
+                if (f) atomicOr(&s_wfound[wv][off >> 5], 1u << (off & 31));
             }
-            if (lane == src) found = hit;
+            const uint32_t fw = s_wfound[wv][lane >> 3];   // the bits of the vertices 4 lane .. 4 lane + 3
+#pragma unroll
+            for (int j = 0; j < 4; j++) found[j] = found[j] || ((fw >> ((4 * lane + j) & 31)) & 1u);
         }
-        const unsigned long long m = __ballot(found);
-        const unsigned long long still = __ballot(active && has_in && !found);
-        if ((threadIdx.x & 63) == 0) {
-            found_bm[t >> 6] = m;
-            cand_out[t >> 6] = still;
+        unsigned long long fb[4], sb[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            fb[j] = __ballot(found[j]);
+            sb[j] = __ballot(h[j] >= 0 && !found[j]);   // still looking, and worth asking again (has in-edges)
+        }
+        if (lane < nw) {
+            const unsigned long long m = bfs_word_of(fb, lane);
+            found_bm[w0 + lane] = m;
+            cand_out[w0 + lane] = bfs_word_of(sb, lane);
+            if (dist_w) found_cnt += (unsigned long long) __popcll(m);
         }
         // single rank: the whole bitmap is this rank's, so dist[] can be settled right here (dist_w aliases dist;
         // a vertex only ever reads its own entry) and the separate apply pass is not needed
-        if (dist_w) {
-            if (found) dist_w[t] = next_level;
-            if ((threadIdx.x & 63) == 0) found_cnt += (unsigned long long) __popcll(m);
+        if (dist_w && (found[0] || found[1] || found[2] || found[3])) {
+            if (!cand_in && v + 3 < V) {   // the lane holds all four entries: one 16-byte store
+                int4 q;
+                q.x = found[0] ? next_level : d4[0]; q.y = found[1] ? next_level : d4[1];
+                q.z = found[2] ? next_level : d4[2]; q.w = found[3] ? next_level : d4[3];
+                *reinterpret_cast<int4*>(dist_w + v) = q;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (found[j]) dist_w[v + j] = next_level;
+            }
         }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) inspected += __shfl_down(inspected, off, 64);
-    if ((threadIdx.x & 63) == 0) bfs_count(ctr, inspected, found_cnt);
+    for (int off = 32; off > 0; off >>= 1) {
+        inspected += __shfl_down(inspected, off, 64);
+        found_cnt += __shfl_down(found_cnt, off, 64);
+    }
+    if (lane == 0) bfs_count(ctr, inspected, found_cnt);
 }
 
 // every rank, whole bitmap: dist[v] = next_level where the bit is set; counts the new frontier
@@ -686,7 +790,7 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
         }
         const int64_t v_lo = (int64_t) b->rank * b->slice_words * 64;
         const int64_t v_hi = v_lo + b->slice_words * 64;
-        hipLaunchKernelGGL(bfs_bottomup_part_kernel, dim3(grid_for(v_hi - v_lo, BFS_THREADS, 256 * 32)), dim3(BFS_THREADS), 0, 0,
+        hipLaunchKernelGGL(bfs_bottomup_part_kernel, dim3(grid_for((v_hi - v_lo + 3) / 4, BFS_THREADS, 256 * 32)), dim3(BFS_THREADS), 0, 0,
                            g->r_begin.p, g->r_node_idx.p, v_lo, v_hi, V, (const uint32_t*) b->bm[b->fr].p,
                            (const int32_t*) b->dist.p, b->bm[1 - b->fr].p, b->nranks == 1 ? b->dist.p : nullptr, b->level + 1, b->ctr.p,
                            b->cand_valid ? (const unsigned long long*) b->cand.p : nullptr, b->cand.p, (const int32_t*) g->bfs_hint.p);
@@ -765,6 +869,9 @@ extern "C" int gmx_bfs_step_end(gmx_bfs_t* b, int64_t* next_count) {
     struct { unsigned long long next_count, next_edges; } h = {b->h_tot->next_count, b->h_tot->next_edges};
     const unsigned long long edges = b->h_tot->edges, found = b->h_tot->found;
     // a top-down level leaves its queue tail in next_count, a bottom-up level its finds in the running total
+    if (getenv("GMX_BFS_DEBUG"))
+        fprintf(stderr, "gmx bfs: level %d %s: frontier %lld -> inspected %llu, next frontier %lld\n", b->level, b->cur_edges == -2 ? "top-down" : "bottom-up",
+                (long long) b->cur_count, edges - b->edges, (long long) (b->cur_edges == -2 ? h.next_count : found - b->found_total));
     b->cur_count = b->cur_edges == -2 ? (int64_t) h.next_count : (int64_t) (found - b->found_total);
     b->found_total = found;
     b->cur_edges = b->cur_edges == -2 ? (int64_t) h.next_edges : -1;

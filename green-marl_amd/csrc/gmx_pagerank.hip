@@ -1772,7 +1772,7 @@ static int pr_build_chunks(gmx_pr* p, int C) {
 // the chunk's rows.  The block holding a chunk boundary belongs to the LATER row chunk, which runs first, so
 // everything a row needs has been computed when its chunk is combined.  The last call closes the step.
 template <typename S>
-static void launch_sliced_chunk(gmx_pr* p, int c, hipStream_t s) {
+static int launch_sliced_chunk(gmx_pr* p, int c, hipStream_t s) {
     const double N = (double) p->V;
     const double base = (1 - p->d) / N;
     const int C = p->nchunks;
@@ -1785,7 +1785,7 @@ static void launch_sliced_chunk(gmx_pr* p, int c, hipStream_t s) {
         const pr_cold_fuse fz{(const int32_t*) p->sl_active.p, (const int32_t*) p->sl_outdeg_c.p, (void*) p->sl_rk_c.p, (void*) next_owned, base, p->d};
         if (c == 0) {
             for (int k = 0; k < 2; k++)
-                if (!(p->gather_mask & (1 << k))) (void) pr_cold_gather(p->cold, p->contrib[p->cur].p, k, s);
+                if (!(p->gather_mask & (1 << k))) GMX_CHECK(pr_cold_gather(p->cold, p->contrib[p->cur].p, k, s));
         }
         double* dfirst = p->diff_part.p + PR_COMBINE_GRID;
         if (c == 0 && p->cnt == 0) {   // first sweep after a reset: settle the rows without in-edges once (all chunks' rows)
@@ -1794,18 +1794,18 @@ static void launch_sliced_chunk(gmx_pr* p, int c, hipStream_t s) {
             hipLaunchKernelGGL(pr_inactive_copy_kernel<S>, dim3(PR_COMBINE_GRID), dim3(256), 0, s, (const uint8_t*) p->sl_is_active.p,
                                p->rows, (S*) p->contrib[p->cur].p + p->row_lo, (const S*) next_owned);
         }
-        if (pr_cold_parts(p->cold) == C) (void) pr_cold_accumulate(p->cold, &fz, c, s);
-        else if (c == 0) (void) pr_cold_accumulate(p->cold, &fz, -1, s);
+        if (pr_cold_parts(p->cold) == C) GMX_CHECK(pr_cold_accumulate(p->cold, &fz, c, s));
+        else if (c == 0) GMX_CHECK(pr_cold_accumulate(p->cold, &fz, -1, s));
         if (c == C - 1) {
             int64_t nd = 0;
             const double* dp = pr_cold_diff_partials(p->cold, &nd);
             hipLaunchKernelGGL(pr_diff_reduce2_kernel, dim3(1), dim3(1024), 0, s, dp, nd, (const double*) dfirst,
                                (int64_t) (p->cnt == 0 ? PR_COMBINE_GRID : 0), p->diff.p);
         }
-        return;
+        return GMX_OK;
     }
     // the binned sources' row sums of ALL rows, once per step, before the first chunk is combined
-    if (c == 0 && p->cold) (void) pr_cold_launch(p->cold, p->contrib[p->cur].p, nullptr, s);
+    if (c == 0 && p->cold) GMX_CHECK(pr_cold_launch(p->cold, p->contrib[p->cur].p, nullptr, s));
     int64_t maxfix = 0, total_blk = 0;
     for (int q = 0; q < p->ns; q++) {
         pr_slice_desc& sd = a.s[q];
@@ -1876,6 +1876,7 @@ static void launch_sliced_chunk(gmx_pr* p, int c, hipStream_t s) {
     if (c == C - 1)   // per chunk: the combine partials, and in the first sweep those of the rows without in-edges
         hipLaunchKernelGGL(pr_diff_reduce_kernel, dim3(1), dim3(1024), 0, s, (const double*) p->diff_part.p, (int64_t) C,
                            (int64_t) 2 * PR_COMBINE_GRID, (int64_t) (p->cnt == 0 ? 2 : 1) * PR_COMBINE_GRID, p->diff.p);
+    return GMX_OK;
 }
 
 extern "C" int gmx_pr_set_chunks(gmx_pr_t* p, int chunks) {
@@ -1953,8 +1954,8 @@ extern "C" int gmx_pr_step_chunk(gmx_pr_t* p, int chunk, void* stream) {
     }
     if (p->ns > 0) {
         if (p->rows > 0) {
-            if (p->elem == 4) launch_sliced_chunk<float>(p, chunk, s);
-            else launch_sliced_chunk<double>(p, chunk, s);
+            if (p->elem == 4) GMX_CHECK(launch_sliced_chunk<float>(p, chunk, s));
+            else GMX_CHECK(launch_sliced_chunk<double>(p, chunk, s));
         }
     } else if (p->nblk > 0) {
         if (p->hot) {

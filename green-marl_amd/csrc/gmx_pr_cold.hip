@@ -1784,13 +1784,25 @@ static void prc_accumulate(pr_cold* c, const pr_cold_fuse& fz, int q, hipStream_
                            fz, c->diffp.p + c->n2 + (a3 + few) * (BINROWS / 64));
 }
 
+// The host mirrors the self-advancing work counters (q1, q1c, q2 += items + grid per launch).  A launch that was refused
+// never advanced its counter, so the mirror would be ahead of the device from then on (the kernels compare unsigned and
+// just end, but every later step would do nothing): bring both back to zero, in stream order, and report the error.
+static int prc_after_launches(pr_cold* c, hipStream_t s) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return GMX_OK;
+    (void) hipMemsetAsync(c->queue.p, 0, 3 * 64 * sizeof(unsigned int), s);
+    c->q1 = c->q1c = c->q2 = 0;
+    gmx_set_error("pr cold: kernel launch failed: %s (work counters reset)", hipGetErrorString(e));
+    return GMX_ERR_HIP;
+}
+
 // Phase 1 of tile class cls (-1: both): reads the contribution replica, fills the value slots of the class's pairs.
 int pr_cold_gather(pr_cold* c, const void* contrib, int cls, hipStream_t s) {
     if (!c || c->Ec == 0 || c->n2 == 0) return GMX_OK;
     const int k0 = cls < 0 ? 0 : cls, k1 = cls < 0 ? 2 : cls + 1;
     if (c->prm.elem == 4) prc_gather<float>(c, contrib, k0, k1, s);
     else prc_gather<double>(c, contrib, k0, k1, s);
-    return GMX_OK;
+    return prc_after_launches(c, s);
 }
 
 // Phases 2-3 of part `part` (-1: all, in processing order).  fuse == NULL: leave the row sums in pr_cold_partial().
@@ -1809,7 +1821,7 @@ int pr_cold_accumulate(pr_cold* c, const pr_cold_fuse* fuse, int part, hipStream
             else prc_accumulate<double, false>(c, none, q, s);
         }
     }
-    return GMX_OK;
+    return prc_after_launches(c, s);
 }
 
 int pr_cold_launch(pr_cold* c, const void* contrib, const pr_cold_fuse* fuse, hipStream_t s) {
