@@ -204,28 +204,56 @@ bfs_topdown_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict_
     if (tid == 0) s_off[nv] = m + 1;   // sentinel
     __syncthreads();
     unsigned long long inspected = 0, deg = 0;
-    for (int64_t x = e0 + tid; x < e1; x += BFS_THREADS) {
-        // frontier slot of edge x: last i with s_off[i] <= x
-        int lo = 0, hi = nv - 1;
-        while (lo < hi) {
-            int mid = (lo + hi + 1) >> 1;
-            if (s_off[mid] <= x) lo = mid; else hi = mid - 1;
+    // A thread's edges (at most BFS_ITEMS / BFS_THREADS) go through the four dependent accesses of an edge -- its slot,
+    // dist[] of the neighbour, the atomicMin, the winner's out-degree -- TOGETHER, one access kind at a time: edge by
+    // edge the level out of a hub (RMAT-26 from vertex 0: 0.98 M edges) was 8 x 4 round trips per thread, 75 us.
+    constexpr int K = BFS_ITEMS / BFS_THREADS;
+    if (e1 > e0) {   // (workgroup-uniform)
+        int32_t sv[K], dv[K], old[K];
+        bool valid[K], won[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int64_t x = e0 + tid + (int64_t) k * BFS_THREADS;
+            valid[k] = x < e1;
+            const int64_t xc = valid[k] ? x : e0;   // (loads stay unconditional: a slot that exists)
+            // frontier slot of edge x: last i with s_off[i] <= x
+            int lo = 0, hi = nv - 1;
+            while (lo < hi) {
+                int mid = (lo + hi + 1) >> 1;
+                if (s_off[mid] <= xc) lo = mid; else hi = mid - 1;
+            }
+            sv[k] = node_idx[(int64_t) s_row[lo] + (xc - s_off[lo])];
+            inspected += valid[k];
         }
-        int32_t s = node_idx[(int64_t) s_row[lo] + (x - s_off[lo])];
-        inspected++;
+#pragma unroll
+        for (int k = 0; k < K; k++) dv[k] = dist[sv[k]];
         // <s.dist_nxt; s.updated_nxt> min= <n.dist + 1; True>   (hop_dist.gm:21)
-        bool won = false;
-        if (dist[s] == INT_MAX) won = (atomicMin(&dist[s], level + 1) == INT_MAX);
-        const unsigned long long mw = __ballot(won);
-        if (mw) {
-            const int lane = tid & 63;
-            const int leader = __ffsll((long long) mw) - 1;
-            unsigned int at = 0;
-            if (lane == leader) at = atomicAdd(&s_nwin, (unsigned int) __popcll(mw));
-            at = __shfl(at, leader, 64);
-            if (won) {
-                s_win[at + __popcll(mw & ((1ULL << lane) - 1))] = s;
-                deg += (unsigned long long) (begin[s + 1] - begin[s]);
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            old[k] = 0;
+            if (valid[k] && dv[k] == INT_MAX) old[k] = atomicMin(&dist[sv[k]], level + 1);
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) won[k] = valid[k] && dv[k] == INT_MAX && old[k] == INT_MAX;
+        int32_t dg[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {   // (unconditional, the losers read row 0: no branch, so the loads overlap)
+            const int32_t r = won[k] ? sv[k] : 0;
+            dg[k] = begin[r + 1] - begin[r];
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const unsigned long long mw = __ballot(won[k]);
+            if (mw) {
+                const int lane = tid & 63;
+                const int leader = __ffsll((long long) mw) - 1;
+                unsigned int at = 0;
+                if (lane == leader) at = atomicAdd(&s_nwin, (unsigned int) __popcll(mw));
+                at = __shfl(at, leader, 64);
+                if (won[k]) {
+                    s_win[at + __popcll(mw & ((1ULL << lane) - 1))] = sv[k];
+                    deg += (unsigned long long) dg[k];
+                }
             }
         }
     }
@@ -298,8 +326,10 @@ __global__ void bfs_level_queue_kernel(const int32_t* __restrict__ dist, int64_t
 // RMAT-26, one per wave as much) and walks its words again to write.
 __global__ void __launch_bounds__(BFS_THREADS)
 bfs_bitmap_queue_kernel(const unsigned long long* __restrict__ bm64, int64_t words,
-                        int32_t* __restrict__ q, unsigned long long* __restrict__ qcount) {
+                        int32_t* __restrict__ q, unsigned long long* __restrict__ qcount,
+                        const int32_t* __restrict__ begin, bfs_counters* __restrict__ ctr /* next_edges += the queue's out-edges */) {
     __shared__ unsigned int s_wave[BFS_THREADS / 64];
+    __shared__ unsigned long long s_deg[BFS_THREADS / 64];
     __shared__ unsigned long long s_base;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t per = (words + gridDim.x - 1) / gridDim.x;
@@ -322,14 +352,27 @@ bfs_bitmap_queue_kernel(const unsigned long long* __restrict__ bm64, int64_t wor
     }
     if (threadIdx.x == 0) s_base = total ? atomicAdd(qcount, (unsigned long long) total) : 0ull;
     __syncthreads();
-    unsigned long long at = s_base + before + (incl - c);
+    unsigned long long at = s_base + before + (incl - c), deg = 0;
     for (int64_t w = lo + threadIdx.x; w < hi; w += BFS_THREADS) {
         unsigned long long m = bm64[w];
         while (m) {
             const int b = __ffsll((long long) m) - 1;
             m &= m - 1;
-            q[at++] = (int32_t) (w * 64 + b);
+            const int64_t v = w * 64 + b;
+            q[at++] = (int32_t) v;
+            deg += (unsigned long long) (begin[v + 1] - begin[v]);
         }
+    }
+    // the queue's out-edges: what the top-down level that follows cuts by merge-path, known to the host with the
+    // level's totals instead of after a scan + copy + stream synchronisation
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) deg += __shfl_down(deg, o, 64);
+    if (lane == 0) s_deg[wv] = deg;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < BFS_THREADS / 64; i++) t += s_deg[i];
+        if (t) atomicAdd(&ctr->next_edges, t);
     }
 }
 
@@ -801,15 +844,23 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
         b->cand_valid = false;         // a top-down level visits vertices the candidate bitmap would still hold
         if (b->frontier_is_bitmap) {   // back from bottom-up: rebuild the queue and its edge offsets
             GMX_HIP(hipMemsetAsync(b->qcount.p, 0, sizeof(unsigned long long), 0));
-            if (b->frontier_bm_valid)   // the frontier is the bitmap the last bottom-up level found
+            if (b->frontier_bm_valid) {   // the frontier is the bitmap the last bottom-up level found
+                // (next_edges is zero here: the bottom-up levels clear it and never add to it)
                 hipLaunchKernelGGL(bfs_bitmap_queue_kernel, dim3(grid_for((V + 63) / 64, BFS_THREADS, 256 * 4)), dim3(BFS_THREADS), 0, 0,
-                                   (const unsigned long long*) b->bm[b->fr].p, (V + 63) / 64, b->cur_q, b->qcount.p);
-            else
+                                   (const unsigned long long*) b->bm[b->fr].p, (V + 63) / 64, b->cur_q, b->qcount.p,
+                                   (const int32_t*) g->begin.p, b->ctr.p);
+                const unsigned long long tag = ++b->tot_tag;
+                hipLaunchKernelGGL(bfs_totals_kernel, dim3(1), dim3(64), 0, 0, (const bfs_counters*) b->ctr.p, b->h_tot, tag);
+                GMX_HIP(hipGetLastError());
+                GMX_CHECK(bfs_wait_totals(b, tag));
+                m_f = (int64_t) b->h_tot->next_edges;   // the offsets follow below, without a read-back
+            } else {
                 hipLaunchKernelGGL(bfs_level_queue_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
                                    (const int32_t*) b->dist.p, V, b->level, b->cur_q, b->qcount.p);
+                GMX_CHECK(bfs_frontier_edges(b, &m_f));
+                have_off = true;
+            }
             b->frontier_is_bitmap = false;
-            GMX_CHECK(bfs_frontier_edges(b, &m_f));
-            have_off = true;
             b->explored += m_f;
         }
         b->frontier_bm_valid = false;
