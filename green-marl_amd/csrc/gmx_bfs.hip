@@ -120,43 +120,55 @@ __global__ void bfs_degree_kernel(const int32_t* __restrict__ begin, const int32
 // workgroup -- the library scan is two launches behind a degree kernel, and with the two read-backs per level that
 // made a level of a small graph cost ~150 us of launches and round trips.  Also clears the counters of the level
 // that is about to run (saves a memset).
-#define BFS_SMALL_SCAN 16384
-#define BFS_SMALL_PER (BFS_SMALL_SCAN / 1024)
+#define BFS_SMALL_CHUNK 16384   // items per pass of the workgroup
+#define BFS_SMALL_PER (BFS_SMALL_CHUNK / 1024)
+// (one pass: a full pass is ~30 us -- 16 K dependent gathers of begin[] from ONE compute unit -- so a second pass already
+// loses against the library scan's three launches; measured at 36.5 K items: 90 us against 49 us)
+#define BFS_SMALL_SCAN BFS_SMALL_CHUNK
 __global__ void __launch_bounds__(1024)
 bfs_degree_scan_small_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ q, int n,
                              int64_t* __restrict__ off, bfs_counters* __restrict__ ctr) {
     __shared__ long long s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    long long d[BFS_SMALL_PER], sum = 0;
+    long long carry = 0;   // degrees of the passes before this one
+    for (int c0 = 0; c0 < n || c0 == 0; c0 += BFS_SMALL_CHUNK) {
+        long long d[BFS_SMALL_PER], sum = 0;
 #pragma unroll
-    for (int j = 0; j < BFS_SMALL_PER; j++) {
-        const int i = tid * BFS_SMALL_PER + j;
-        d[j] = 0;
-        if (i < n) {
-            const int32_t v = q[i];
-            d[j] = begin[v + 1] - begin[v];
+        for (int j = 0; j < BFS_SMALL_PER; j++) {
+            const int i = c0 + tid * BFS_SMALL_PER + j;
+            d[j] = 0;
+            if (i < n) {
+                const int32_t v = q[i];
+                d[j] = begin[v + 1] - begin[v];
+            }
+            sum += d[j];
         }
-        sum += d[j];
-    }
-    long long incl = sum;   // inclusive scan of the threads' sums: inside the wave, then over the 16 waves
+        long long incl = sum;   // inclusive scan of the threads' sums: inside the wave, then over the 16 waves
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const long long t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_wave[wv] = incl;
-    __syncthreads();
-    long long wbase = 0;
-    for (int w = 0; w < wv; w++) wbase += s_wave[w];
-    long long run = wbase + incl - sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (c0) __syncthreads();   // (the previous pass has read s_wave)
+        if (lane == 63) s_wave[wv] = incl;
+        __syncthreads();
+        long long wbase = carry, total = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < wv) wbase += s_wave[w];
+            total += s_wave[w];
+        }
+        long long run = wbase + incl - sum;
 #pragma unroll
-    for (int j = 0; j < BFS_SMALL_PER; j++) {
-        const int i = tid * BFS_SMALL_PER + j;
-        if (i < n) off[i] = run;
-        run += d[j];
-        if (i == n - 1) off[n] = run;
+        for (int j = 0; j < BFS_SMALL_PER; j++) {
+            const int i = c0 + tid * BFS_SMALL_PER + j;
+            if (i < n) off[i] = run;
+            run += d[j];
+            if (i == n - 1) off[n] = run;
+        }
+        carry += total;
     }
     if (tid == 0) {
+        if (n == 0) off[0] = 0;
         ctr->next_count = 0;
         ctr->next_edges = 0;
     }
@@ -423,6 +435,7 @@ struct gmx_bfs {
     bool cand_valid = false;
     dbuf<unsigned long long> bm[2];   // frontier / found, swapped after every bottom-up level
     int fr = 0;                       // bm[fr] = frontier, bm[1 - fr] = found
+    bool bm_clean[2] = {false, false};   // all zero (since bfs_init_kernel): the first switch to bottom-up needs no memset
     dbuf<bfs_counters> ctr;
     dbuf<unsigned long long> qcount;
     int32_t level = 0;
@@ -780,6 +793,7 @@ extern "C" int gmx_bfs_start(gmx_bfs_t* b, gmx_node_t root) {
     b->frontier_is_bitmap = b->frontier_bm_valid = b->pending_bottom_up = false;
     b->cand_valid = false;
     b->fr = 0;
+    b->bm_clean[0] = b->bm_clean[1] = true;   // bfs_init_kernel clears both
     b->cur_q = b->q0.p;
     b->next_q = b->q1.p;
     b->cur_edges = -1;
@@ -824,13 +838,14 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
         GMX_HIP(hipMemsetAsync(&b->ctr.p->next_count, 0, 2 * sizeof(unsigned long long), 0));   // next_count, next_edges; `edges` keeps accumulating
         if (!b->frontier_bm_valid) {   // first bottom-up level after queue levels: frontier = {v : dist[v] == level}
             if (!b->frontier_is_bitmap) {   // ... which is the queue the last top-down level wrote
-                GMX_HIP(hipMemsetAsync(b->bm[b->fr].p, 0, sizeof(unsigned long long) * (size_t) b->words, 0));
+                if (!b->bm_clean[b->fr]) GMX_HIP(hipMemsetAsync(b->bm[b->fr].p, 0, sizeof(unsigned long long) * (size_t) b->words, 0));
                 hipLaunchKernelGGL(bfs_queue_bitmap_kernel, dim3(grid_for(b->cur_count, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
                                    (const int32_t*) b->cur_q, b->cur_count, (unsigned int*) b->bm[b->fr].p);
             } else
                 hipLaunchKernelGGL(bfs_level_bitmap_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
                                    (const int32_t*) b->dist.p, V, b->level, b->bm[b->fr].p);
         }
+        b->bm_clean[0] = b->bm_clean[1] = false;   // the frontier was just written, the level writes the other one
         const int64_t v_lo = (int64_t) b->rank * b->slice_words * 64;
         const int64_t v_hi = v_lo + b->slice_words * 64;
         hipLaunchKernelGGL(bfs_bottomup_part_kernel, dim3(grid_for((v_hi - v_lo + 3) / 4, BFS_THREADS, 256 * 32)), dim3(BFS_THREADS), 0, 0,
