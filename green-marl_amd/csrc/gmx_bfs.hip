@@ -434,6 +434,7 @@ struct gmx_bfs {
     dbuf<unsigned long long> cand;    // unvisited vertices with in-edges, kept from one bottom-up level to the next
     bool cand_valid = false;
     dbuf<unsigned long long> bm[2];   // frontier / found, swapped after every bottom-up level
+    dbuf<unsigned long long> hub_bits;   // [BFS_HUBS / 64] the frontier bits of the graph's hubs, rebuilt before every bottom-up level
     int fr = 0;                       // bm[fr] = frontier, bm[1 - fr] = found
     bool bm_clean[2] = {false, false};   // all zero (since bfs_init_kernel): the first switch to bottom-up needs no memset
     dbuf<bfs_counters> ctr;
@@ -465,8 +466,26 @@ struct gmx_bfs {
 // without touching its row; at RMAT-26 the first bottom-up level otherwise streams the whole reverse CSR (4.3 GB)
 // because every unvisited vertex reads at least the first line of its row.
 #define BFS_HINT_SCAN 32
+// Encoding of hint[v] (unless the graph has more than 2^30 vertices: then plain ids, -1 = none):
+//   -1                         no in-edges at all
+//   bit 31 (BFS_H_ONLY)        the hint is the ONLY in-neighbour: when it misses there is no row to walk.  RMAT-26 from
+//                              vertex 0: 76 % of the vertices the first bottom-up level leaves without a parent have
+//                              in-degree 1 (they are the ones found late, or never), 99.5 % in the later levels -- and a
+//                              failed walk has no early exit.
+//   bit 30 (BFS_H_HUB)         the low bits are a SLOT of the graph's hub list (the BFS_HUBS vertices with most out-edges),
+//                              not a vertex id: its frontier bit is probed in the workgroup's LDS copy of the hubs' bits.
+//                              The hint probes are what a bottom-up level spends most of its time on once dist[] and
+//                              hint[] stream at the HBM rate (RMAT-26, first level: 27.7 M probes, one 64-byte request for
+//                              four useful bytes each, 165 of 450 us); offline on RMAT-22, 72 % of the hints of the
+//                              vertices looking in that level are among the V/512 vertices with most out-edges.
+#define BFS_H_ONLY 0x80000000u
+#define BFS_H_HUB 0x40000000u
+#define BFS_H_MASK 0x3FFFFFFFu
+#define BFS_HUBS 131072   // 16 KiB of LDS per workgroup
+#define BFS_HUB_MIN_V (1LL << 25)
 __global__ void bfs_hint_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ r_begin,
-                                const int32_t* __restrict__ r_node_idx, int64_t V, int32_t* __restrict__ hint) {
+                                const int32_t* __restrict__ r_node_idx, int64_t V, const int32_t* __restrict__ slot_of /* NULL: slot = id */,
+                                int plain, int32_t* __restrict__ hint) {
     int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
     for (; v < V; v += stride) {
@@ -481,12 +500,41 @@ __global__ void bfs_hint_kernel(const int32_t* __restrict__ begin, const int32_t
                 best = w;
             }
         }
-        // A vertex with ONE in-edge has nothing else to look at when the hint misses: it is stored as -2 - w, and the
-        // bottom-up level then skips the row (r_begin[], the row's line, a second probe of the same bit).  RMAT-26 from
-        // vertex 0: 76 % of the vertices the first bottom-up level leaves without a parent have in-degree 1 (they are the
-        // ones found late, or never), 99.5 % in the later levels -- and a failed walk has no early exit.
-        hint[v] = e - b == 1 ? -2 - best : best;
+        if (best < 0 || plain) {
+            hint[v] = best;
+            continue;
+        }
+        const int32_t slot = slot_of ? slot_of[best] : -1;   // (no hub list: ids only)
+        uint32_t code = slot >= 0 ? (BFS_H_HUB | (uint32_t) slot) : (uint32_t) best;
+        if (e - b == 1) code |= BFS_H_ONLY;
+        hint[v] = (int32_t) code;
     }
+}
+
+// hub list: keys for the sort by out-degree, the slot table, and a level's hub bits
+__global__ void bfs_degkey_kernel(const int32_t* __restrict__ begin, int64_t V, uint32_t* __restrict__ key, int32_t* __restrict__ id) {
+    int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; v < V; v += stride) {
+        key[v] = (uint32_t) (begin[v + 1] - begin[v]);
+        id[v] = (int32_t) v;
+    }
+}
+__global__ void bfs_slot_of_kernel(const int32_t* __restrict__ hub_id, int n, int32_t* __restrict__ slot_of) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) slot_of[hub_id[s]] = s;
+}
+// hub_bits[s / 32] bit s % 32 = frontier bit of hub s (n a multiple of 64: the list is padded with vertex 0)
+__global__ void bfs_hub_bits_kernel(const uint32_t* __restrict__ frontier_bm, const int32_t* __restrict__ hub_id, int n,
+                                    unsigned long long* __restrict__ hub_bits) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    bool bit = false;
+    if (s < n) {
+        const int32_t v = hub_id[s];
+        bit = (frontier_bm[v >> 5] >> (v & 31)) & 1u;
+    }
+    const unsigned long long m = __ballot(bit);
+    if ((threadIdx.x & 63) == 0 && s < n) hub_bits[s >> 6] = m;
 }
 
 #define BFS_BU_OWN 32   // in-row entries a vertex checks alone before its wave helps
@@ -526,13 +574,17 @@ bfs_bottomup_part_kernel(const int32_t* __restrict__ r_begin, const int32_t* __r
                          const int32_t* dist, unsigned long long* __restrict__ found_bm,
                          int32_t* dist_w /* NULL or == dist */, int32_t next_level, bfs_counters* __restrict__ ctr,
                          const unsigned long long* cand_in /* NULL: take the unvisited from dist[] */,
-                         unsigned long long* cand_out, const int32_t* __restrict__ hint) {
+                         unsigned long long* cand_out, const int32_t* __restrict__ hint, int plain,
+                         const uint32_t* __restrict__ hub_bits, int hub_words /* > 0: probe the hubs in an LDS copy */) {
+    __shared__ uint32_t s_hub[BFS_HUBS / 32];             // the frontier bits of the hubs, by slot (see BFS_H_HUB)
     __shared__ uint8_t s_walk[BFS_THREADS / 64][256];     // offsets (0..255) of the wave step's vertices that walk their row
     __shared__ uint32_t s_wfound[BFS_THREADS / 64][8];    // ... and which of them found a parent
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t nwaves = (int64_t) gridDim.x * (BFS_THREADS / 64);
     const int64_t word_hi = v_hi >> 6;
     unsigned long long inspected = 0, found_cnt = 0;
+    for (int i = threadIdx.x; i < hub_words; i += BFS_THREADS) s_hub[i] = hub_bits[i];
+    __syncthreads();
     for (int64_t w0 = (v_lo >> 6) + 4 * ((int64_t) blockIdx.x * (BFS_THREADS / 64) + wv); w0 < word_hi; w0 += 4 * nwaves) {
         const int nw = word_hi - w0 < 4 ? (int) (word_hi - w0) : 4;   // words of this step (wave-uniform)
         const int64_t v = w0 * 64 + 4 * lane;                         // this lane's vertices: v .. v + 3
@@ -569,14 +621,32 @@ bfs_bottomup_part_kernel(const int32_t* __restrict__ r_begin, const int32_t* __r
                 for (int j = 0; j < 4; j++) h[j] = v + j < V ? hint[v + j] : -1;
             }
         }
-        bool only[4], found[4], need[4];
+        bool only[4], found[4], need[4], hub[4];
         uint32_t probe[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (!active[j]) h[j] = -1;
-            only[j] = h[j] < -1;               // -2 - w: w is the only in-neighbour
-            if (only[j]) h[j] = -2 - h[j];
-            probe[j] = frontier_bm[(h[j] >= 0 ? h[j] : 0) >> 5];   // (unconditional: four loads in flight, no branches between them)
+            const uint32_t raw = (uint32_t) h[j];
+            const bool coded = !plain && h[j] != -1;
+            only[j] = coded && (raw & BFS_H_ONLY);
+            hub[j] = coded && (raw & BFS_H_HUB);
+            if (coded) h[j] = (int32_t) (raw & BFS_H_MASK);   // a vertex id, or a hub slot
+        }
+        // (the probes are unconditional, from a harmless address where they do not apply: four loads in flight, no branches
+        // between them)
+        if (hub_words > 0) {   // (kernel argument: uniform)  hubs in the LDS copy, the others in the frontier bitmap
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t g = frontier_bm[(h[j] >= 0 && !hub[j] ? h[j] : 0) >> 5];
+                const uint32_t l = s_hub[(hub[j] ? h[j] : 0) >> 5];
+                probe[j] = hub[j] ? l : g;
+            }
+        } else {               // one load either way: the hubs' bits are a 16 KiB array in memory
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t* base = hub[j] ? hub_bits : frontier_bm;
+                probe[j] = base[(h[j] >= 0 ? h[j] : 0) >> 5];
+            }
         }
         bool any_need = false;
 #pragma unroll
@@ -702,6 +772,43 @@ __global__ void bfs_apply_found_kernel(const unsigned long long* __restrict__ fo
     if ((threadIdx.x & 63) == 0) bfs_count(ctr, 0, cnt);
 }
 
+// The per-graph preprocessing of the bottom-up levels: the hub list (BFS_HUBS vertices with most out-edges) and hint[].
+static int bfs_build_hints(gmx_graph* g) {
+    const int64_t V = g->V;
+    GMX_CHECK(g->bfs_hint.alloc((size_t) (V ? V : 1)));
+    g->bfs_hint_plain = V > (int64_t) BFS_H_MASK;
+    // hubs only where a bottom-up level is long enough to gain from them: below 2^25 vertices the extra launch per level
+    // (the hubs' bits) cost more than the probes it saved (RMAT-20/22/24: 5-10 % slower with hubs, RMAT-26: 10 % faster)
+    g->bfs_hubs = !g->bfs_hint_plain && V >= BFS_HUB_MIN_V ? BFS_HUBS : 0;
+    if (V == 0) return GMX_OK;
+    gmx_ws_scope scope;   // (temporaries from the workspace: see gmx_internal.h)
+    wbuf<int32_t> slot_of;
+    if (g->bfs_hubs > 0) {
+        wbuf<uint32_t> key, key2;
+        wbuf<int32_t> id, id2;
+        wbuf<char> tmp;
+        GMX_CHECK(key.alloc((size_t) V));
+        GMX_CHECK(key2.alloc((size_t) V));
+        GMX_CHECK(id.alloc((size_t) V));
+        GMX_CHECK(id2.alloc((size_t) V));
+        GMX_CHECK(slot_of.alloc((size_t) V));
+        GMX_CHECK(g->bfs_hub_id.alloc((size_t) BFS_HUBS));
+        hipLaunchKernelGGL(bfs_degkey_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, (const int32_t*) g->begin.p, V, key.p, id.p);
+        size_t tb = 0;
+        GMX_HIP(rocprim::radix_sort_pairs_desc(nullptr, tb, key.p, key2.p, id.p, id2.p, (size_t) V, 0u, 32u, 0));
+        GMX_CHECK(tmp.alloc(tb));
+        GMX_HIP(rocprim::radix_sort_pairs_desc((void*) tmp.p, tb, key.p, key2.p, id.p, id2.p, (size_t) V, 0u, 32u, 0));
+        GMX_HIP(hipMemcpyAsync(g->bfs_hub_id.p, id2.p, sizeof(int32_t) * BFS_HUBS, hipMemcpyDeviceToDevice, 0));
+        GMX_HIP(hipMemsetAsync(slot_of.p, 0xFF, sizeof(int32_t) * (size_t) V, 0));
+        hipLaunchKernelGGL(bfs_slot_of_kernel, dim3(BFS_HUBS / BFS_THREADS), dim3(BFS_THREADS), 0, 0, (const int32_t*) g->bfs_hub_id.p, BFS_HUBS, slot_of.p);
+    }
+    hipLaunchKernelGGL(bfs_hint_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, (const int32_t*) g->begin.p,
+                       (const int32_t*) g->r_begin.p, (const int32_t*) g->r_node_idx.p, V, (const int32_t*) slot_of.p,
+                       g->bfs_hint_plain ? 1 : 0, g->bfs_hint.p);
+    GMX_HIP(hipGetLastError());
+    return GMX_OK;   // (the scope's destructor waits for the kernels before the temporaries are handed out again)
+}
+
 extern "C" int gmx_bfs_create(gmx_graph_t* g, int rank, int nranks, gmx_bfs_t** out) {
     GMX_REQUIRE(out, "out is NULL");
     *out = nullptr;
@@ -709,12 +816,7 @@ extern "C" int gmx_bfs_create(gmx_graph_t* g, int rank, int nranks, gmx_bfs_t** 
     GMX_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d / nranks %d", rank, nranks);
     GMX_REQUIRE(nranks == 1 || g->has_reverse, "the partitioned traversal needs the reverse CSR");
     if (g->has_reverse && !g->bfs_hint.p) {   // graph preprocessing for the bottom-up levels
-        GMX_CHECK(g->bfs_hint.alloc((size_t) (g->V ? g->V : 1)));
-        if (g->V > 0) {
-            hipLaunchKernelGGL(bfs_hint_kernel, dim3(grid_for(g->V)), dim3(BFS_THREADS), 0, 0, (const int32_t*) g->begin.p,
-                               (const int32_t*) g->r_begin.p, (const int32_t*) g->r_node_idx.p, g->V, g->bfs_hint.p);
-            GMX_HIP(hipGetLastError());
-        }
+        GMX_CHECK(bfs_build_hints(g));
     }
     gmx_bfs* b = new gmx_bfs();
     b->g = g;
@@ -729,7 +831,8 @@ extern "C" int gmx_bfs_create(gmx_graph_t* g, int rank, int nranks, gmx_bfs_t** 
     int st = GMX_OK;
     if ((st = b->dist.alloc(V1)) || (st = b->q0.alloc(V1)) || (st = b->q1.alloc(V1)) || (st = b->deg.alloc(V1)) ||
         (st = b->off.alloc(V1 + 2)) || (st = b->ctr.alloc(1)) || (st = b->qcount.alloc(1)) ||
-        (st = b->bm[0].alloc((size_t) b->words)) || (st = b->bm[1].alloc((size_t) b->words)) || (st = b->cand.alloc((size_t) b->words))) {
+        (st = b->bm[0].alloc((size_t) b->words)) || (st = b->bm[1].alloc((size_t) b->words)) || (st = b->cand.alloc((size_t) b->words)) ||
+        (st = b->hub_bits.alloc(BFS_HUBS / 64))) {
         delete b;
         return st;
     }
@@ -848,10 +951,24 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
         b->bm_clean[0] = b->bm_clean[1] = false;   // the frontier was just written, the level writes the other one
         const int64_t v_lo = (int64_t) b->rank * b->slice_words * 64;
         const int64_t v_hi = v_lo + b->slice_words * 64;
-        hipLaunchKernelGGL(bfs_bottomup_part_kernel, dim3(grid_for((v_hi - v_lo + 3) / 4, BFS_THREADS, 256 * 32)), dim3(BFS_THREADS), 0, 0,
+        // the hubs' frontier bits, by slot
+        const uint32_t* hub_bits = (const uint32_t*) b->bm[b->fr].p;   // (no hub list: never read through a slot)
+        int hub_words = 0;
+        if (g->bfs_hub_id.p) {
+            hipLaunchKernelGGL(bfs_hub_bits_kernel, dim3(BFS_HUBS / BFS_THREADS), dim3(BFS_THREADS), 0, 0, (const uint32_t*) b->bm[b->fr].p,
+                               (const int32_t*) g->bfs_hub_id.p, BFS_HUBS, b->hub_bits.p);
+            hub_bits = (const uint32_t*) b->hub_bits.p;
+            hub_words = BFS_HUBS / 32;
+        }
+        // The LDS copy (16 KiB per workgroup, filled once by each of one resident set of workgroups) pays where the level is
+        // long: the first bottom-up level of a run over at least 2^25 vertices (RMAT-26: 450 -> 323 us; the later levels, with
+        // a fifth of the vertices still looking, were slower with it).  Otherwise the same 16 KiB are probed in memory.
+        const bool use_lds = hub_words > 0 && !b->cand_valid && v_hi - v_lo >= BFS_HUB_MIN_V;
+        hipLaunchKernelGGL(bfs_bottomup_part_kernel, dim3(grid_for((v_hi - v_lo + 3) / 4, BFS_THREADS, use_lds ? 256 * 7 : 256 * 32)), dim3(BFS_THREADS), 0, 0,
                            g->r_begin.p, g->r_node_idx.p, v_lo, v_hi, V, (const uint32_t*) b->bm[b->fr].p,
                            (const int32_t*) b->dist.p, b->bm[1 - b->fr].p, b->nranks == 1 ? b->dist.p : nullptr, b->level + 1, b->ctr.p,
-                           b->cand_valid ? (const unsigned long long*) b->cand.p : nullptr, b->cand.p, (const int32_t*) g->bfs_hint.p);
+                           b->cand_valid ? (const unsigned long long*) b->cand.p : nullptr, b->cand.p, (const int32_t*) g->bfs_hint.p,
+                           g->bfs_hint_plain ? 1 : 0, hub_bits, use_lds ? hub_words : 0);
         b->cand_valid = true;
         b->pending_bottom_up = true;
         *needs_exchange = b->nranks > 1 ? 1 : 0;

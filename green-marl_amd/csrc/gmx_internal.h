@@ -132,6 +132,11 @@ struct gmx_graph {
     // bottom-up BFS: per vertex the in-neighbour to try first (the one with most out-edges among the first of its
     // in-row; -1: no in-edges).  Graph preprocessing like the reverse CSR, built with the first traversal object.
     dbuf<int32_t> bfs_hint;
+    // ... and the BFS_HUBS vertices with most out-edges ("hubs"; all vertices if there are fewer): a hint that is a hub is
+    // stored as its slot in this list, and a bottom-up level probes the hubs' frontier bits in LDS (gmx_bfs.hip)
+    dbuf<int32_t> bfs_hub_id;     // [bfs_hubs]; empty when every vertex is a hub (slot = id)
+    int64_t bfs_hubs = 0;
+    bool bfs_hint_plain = false;  // V > 2^30: the hints are plain vertex ids (no room for the flag bits)
 };
 
 // ---- graph construction helpers (gmx_graph.hip) ----
