@@ -289,6 +289,82 @@ bfs_topdown_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict_
     for (unsigned int i = tid; i < nwin; i += BFS_THREADS) next_q[s_base + i] = s_win[i];
 }
 
+// The level out of the ROOT (every traversal's first): one row, nobody else visited.  Its distinct entries (the rows are
+// sorted: a repeated edge sits next to its copy) other than the root itself all get level + 1 -- no look at dist[], no
+// atomicMin: the general kernel spent 75-84 us on the 0.98 M out-edges of RMAT-26's vertex 0, four dependent random accesses
+// per edge.  With bm32 the frontier bitmap of the next level is written here too (a large row is followed by a bottom-up
+// level, which otherwise starts with a pass over the new queue: 35 us).
+__global__ void __launch_bounds__(BFS_THREADS)
+bfs_first_level_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx, int32_t root, int32_t level,
+                       int32_t* __restrict__ dist, int32_t* __restrict__ next_q, bfs_counters* __restrict__ ctr,
+                       unsigned int* __restrict__ bm32 /* or NULL */) {
+    __shared__ int32_t s_win[BFS_ITEMS];
+    __shared__ unsigned int s_nwin;
+    __shared__ unsigned long long s_deg, s_base;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) {
+        s_nwin = 0;
+        s_deg = 0;
+    }
+    __syncthreads();
+    const int32_t b = begin[root], e = begin[root + 1];
+    constexpr int K = BFS_ITEMS / BFS_THREADS;
+    const int32_t x0 = b + (int32_t) blockIdx.x * BFS_ITEMS;   // (the grid covers e - b)
+    int32_t sv[K], pv[K], dg[K];
+    bool won[K];
+    unsigned long long inspected = 0, deg = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int32_t x = x0 + tid + k * BFS_THREADS;
+        const int32_t xc = x < e ? x : e - 1;
+        sv[k] = node_idx[xc];
+        pv[k] = xc > b ? node_idx[xc - 1] : -1;
+        won[k] = x < e && sv[k] != root && sv[k] != pv[k];
+        inspected += x < e;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {   // (unconditional, the others read row 0: no branch, so the loads overlap)
+        const int32_t r = won[k] ? sv[k] : 0;
+        dg[k] = begin[r + 1] - begin[r];
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if (won[k]) {
+            dist[sv[k]] = level + 1;
+            if (bm32) atomicOr(&bm32[sv[k] >> 5], 1u << (sv[k] & 31));
+        }
+        const unsigned long long mw = __ballot(won[k]);
+        if (mw) {
+            const int leader = __ffsll((long long) mw) - 1;
+            unsigned int at = 0;
+            if (lane == leader) at = atomicAdd(&s_nwin, (unsigned int) __popcll(mw));
+            at = __shfl(at, leader, 64);
+            if (won[k]) {
+                s_win[at + __popcll(mw & ((1ULL << lane) - 1))] = sv[k];
+                deg += (unsigned long long) dg[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        inspected += __shfl_down(inspected, o, 64);
+        deg += __shfl_down(deg, o, 64);
+    }
+    if (lane == 0) {
+        bfs_count(ctr, inspected, 0);
+        if (deg) atomicAdd(&s_deg, deg);
+    }
+    __syncthreads();
+    const unsigned int nwin = s_nwin;
+    if (nwin == 0) return;   // (workgroup-uniform)
+    if (tid == 0) {
+        s_base = atomicAdd(&ctr->next_count, (unsigned long long) nwin);
+        if (s_deg) atomicAdd(&ctr->next_edges, s_deg);
+    }
+    __syncthreads();
+    for (unsigned int i = tid; i < nwin; i += BFS_THREADS) next_q[s_base + i] = s_win[i];
+}
+
 // frontier bitmap of a level straight from dist[] (coalesced reads, one __ballot per 64 vertices, no atomics)
 __global__ void bfs_level_bitmap_kernel(const int32_t* __restrict__ dist, int64_t V, int32_t level,
                                         unsigned long long* __restrict__ bm64) {
@@ -436,6 +512,8 @@ struct gmx_bfs {
     dbuf<unsigned long long> bm[2];   // frontier / found, swapped after every bottom-up level
     dbuf<unsigned long long> hub_bits;   // [BFS_HUBS / 64] the frontier bits of the graph's hubs, rebuilt before every bottom-up level
     int fr = 0;                       // bm[fr] = frontier, bm[1 - fr] = found
+    int32_t root = -1;
+    int first_bm_level = -1;          // >= 0: bm[fr] already holds the frontier of this level (written by bfs_first_level_kernel)
     bool bm_clean[2] = {false, false};   // all zero (since bfs_init_kernel): the first switch to bottom-up needs no memset
     dbuf<bfs_counters> ctr;
     dbuf<unsigned long long> qcount;
@@ -897,6 +975,8 @@ extern "C" int gmx_bfs_start(gmx_bfs_t* b, gmx_node_t root) {
     b->cand_valid = false;
     b->fr = 0;
     b->bm_clean[0] = b->bm_clean[1] = true;   // bfs_init_kernel clears both
+    b->root = root_ok ? (int32_t) root : -1;
+    b->first_bm_level = -1;
     b->cur_q = b->q0.p;
     b->next_q = b->q1.p;
     b->cur_edges = -1;
@@ -940,7 +1020,9 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
     if (bottom_up) {
         GMX_HIP(hipMemsetAsync(&b->ctr.p->next_count, 0, 2 * sizeof(unsigned long long), 0));   // next_count, next_edges; `edges` keeps accumulating
         if (!b->frontier_bm_valid) {   // first bottom-up level after queue levels: frontier = {v : dist[v] == level}
-            if (!b->frontier_is_bitmap) {   // ... which is the queue the last top-down level wrote
+            if (!b->frontier_is_bitmap && b->first_bm_level == b->level) {
+                // ... which the level out of the root has written already
+            } else if (!b->frontier_is_bitmap) {   // ... which is the queue the last top-down level wrote
                 if (!b->bm_clean[b->fr]) GMX_HIP(hipMemsetAsync(b->bm[b->fr].p, 0, sizeof(unsigned long long) * (size_t) b->words, 0));
                 hipLaunchKernelGGL(bfs_queue_bitmap_kernel, dim3(grid_for(b->cur_count, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0,
                                    (const int32_t*) b->cur_q, b->cur_count, (unsigned int*) b->bm[b->fr].p);
@@ -996,6 +1078,26 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
             b->explored += m_f;
         }
         b->frontier_bm_valid = false;
+        if (b->level == 0 && b->cur_count == 1 && b->root >= 0 && !have_off) {   // the level out of the root
+            // (the counters are clear: bfs_init_kernel)  A row this large is followed by a bottom-up level: write its bitmap too
+            // (liberal: a wrong guess costs a memset of the bitmap later, a missed one a pass over the queue now)
+            const bool with_bm = g->has_reverse && b->bm_clean[b->fr] && m_f >= 64 && m_f >= V / 1024;
+            const int64_t nb1 = (m_f + BFS_ITEMS - 1) / BFS_ITEMS;
+            if (nb1 > 0)
+                hipLaunchKernelGGL(bfs_first_level_kernel, dim3((unsigned) nb1), dim3(BFS_THREADS), 0, 0, (const int32_t*) g->begin.p,
+                                   (const int32_t*) g->node_idx.p, b->root, b->level, b->dist.p, b->next_q, b->ctr.p,
+                                   with_bm ? (unsigned int*) b->bm[b->fr].p : nullptr);
+            if (with_bm && nb1 > 0) {
+                b->bm_clean[b->fr] = false;
+                b->first_bm_level = 1;
+            }
+            int32_t* t = b->cur_q;
+            b->cur_q = b->next_q;
+            b->next_q = t;
+            b->cur_edges = -2;
+            GMX_HIP(hipGetLastError());
+            return GMX_OK;
+        }
         if (!have_off) {   // merge-path offsets of the queue
             if (b->cur_count <= BFS_SMALL_SCAN) {
                 hipLaunchKernelGGL(bfs_degree_scan_small_kernel, dim3(1), dim3(1024), 0, 0, g->begin.p, (const int32_t*) b->cur_q,
