@@ -1018,7 +1018,8 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
         b->explored += m_f;
     }
     if (bottom_up) {
-        GMX_HIP(hipMemsetAsync(&b->ctr.p->next_count, 0, 2 * sizeof(unsigned long long), 0));   // next_count, next_edges; `edges` keeps accumulating
+        // (next_count / next_edges are top-down counters: a bottom-up level neither reads nor writes them, and the switch back
+        // to top-down clears them where it needs them -- a memset here was a launch slot of ~7 us per level)
         if (!b->frontier_bm_valid) {   // first bottom-up level after queue levels: frontier = {v : dist[v] == level}
             if (!b->frontier_is_bitmap && b->first_bm_level == b->level) {
                 // ... which the level out of the root has written already
@@ -1059,7 +1060,7 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
         if (b->frontier_is_bitmap) {   // back from bottom-up: rebuild the queue and its edge offsets
             GMX_HIP(hipMemsetAsync(b->qcount.p, 0, sizeof(unsigned long long), 0));
             if (b->frontier_bm_valid) {   // the frontier is the bitmap the last bottom-up level found
-                // (next_edges is zero here: the bottom-up levels clear it and never add to it)
+                GMX_HIP(hipMemsetAsync(&b->ctr.p->next_count, 0, 2 * sizeof(unsigned long long), 0));   // next_count, next_edges
                 hipLaunchKernelGGL(bfs_bitmap_queue_kernel, dim3(grid_for((V + 63) / 64, BFS_THREADS, 256 * 4)), dim3(BFS_THREADS), 0, 0,
                                    (const unsigned long long*) b->bm[b->fr].p, (V + 63) / 64, b->cur_q, b->qcount.p,
                                    (const int32_t*) g->begin.p, b->ctr.p);
