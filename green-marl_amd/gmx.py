@@ -260,11 +260,11 @@ class Graph:
     def download(self, reverse=True):
         V, E = self.V, self.E
         begin = np.empty(V + 1, np.int32)
-        node_idx = np.empty(max(E, 1), np.int32)[:E].copy()
+        node_idx = np.empty(E, np.int32)
         rb = rn = None
         if reverse:
             rb = np.empty(V + 1, np.int32)
-            rn = np.empty(max(E, 1), np.int32)[:E].copy()
+            rn = np.empty(E, np.int32)
         _ck(lib().gmx_graph_download(self._h, begin.ctypes.data, node_idx.ctypes.data,
                                      rb.ctypes.data if reverse else None, rn.ctypes.data if reverse else None))
         return begin, node_idx, rb, rn
@@ -283,7 +283,7 @@ class Graph:
     # -- the three kernels (mirror of the generated entry points) ----------
     def pagerank(self, e=0.001, d=0.85, max_iter=100, dtype=np.float64):
         """pagerank(G, e, d, max, G_pg_rank) -- returns (rank, stats)."""
-        rank = np.empty(max(self.V, 1), dtype)[: self.V].copy()
+        rank = np.empty(self.V, dtype)
         st = Stats()
         if dtype == np.float64:
             _ck(lib().gmx_pagerank_f64(self._h, e, d, max_iter, rank.ctypes.data, C.byref(st)))
@@ -295,14 +295,14 @@ class Graph:
 
     def hop_dist(self, root=0):
         """hop_dist(G, G_dist, root) -- returns (dist, stats)."""
-        dist = np.empty(max(self.V, 1), np.int32)[: self.V].copy()
+        dist = np.empty(self.V, np.int32)
         st = Stats()
         _ck(lib().gmx_hop_dist(self._h, root, dist.ctypes.data, C.byref(st)))
         return dist, st.as_dict()
 
     def bfs_levels(self, root=0):
         """prepare(root) + do_bfs_forward() of the BFS object -> (level[int16], unvisited = -2; number of levels)."""
-        lv = np.zeros(max(self.V, 1), np.int16)[:self.V].copy()
+        lv = np.zeros(self.V, np.int16)
         n = C.c_int32(0)
         _ck(lib().gmx_bfs_levels(self._h, int(root), lv.ctypes.data, C.byref(n)))
         return lv, n.value
@@ -310,7 +310,7 @@ class Graph:
     def bc(self, seeds, skip_root=False):
         """comp_BC(G, BC, Seeds) of bc.gm -> (BC[float32], stats)."""
         seeds = _i32(seeds)
-        out = np.zeros(max(self.V, 1), np.float32)[:self.V].copy()
+        out = np.zeros(self.V, np.float32)
         st = Stats()
         _ck(lib().gmx_bc(self._h, seeds.ctypes.data if len(seeds) else None, len(seeds), int(bool(skip_root)), out.ctypes.data, C.byref(st)))
         return out, st.as_dict()
@@ -319,7 +319,7 @@ class Graph:
         """sssp(G, dist, len, root): length[E] int32 by forward edge slot -- returns (dist[int32], stats)."""
         length = _i32(length)
         assert len(length) == self.E
-        dist = np.zeros(max(self.V, 1), np.int32)[:self.V].copy()
+        dist = np.zeros(self.V, np.int32)
         st = Stats()
         _ck(lib().gmx_sssp(self._h, int(root), length.ctypes.data if self.E else None, dist.ctypes.data, C.byref(st)))
         return dist, st.as_dict()
@@ -328,7 +328,7 @@ class Graph:
         """avg_teen_cnt(G, age, teen_cnt, K) -- returns (avg float32, teen_cnt[int32], stats)."""
         age = _i32(age)
         assert len(age) == self.V
-        cnt = np.zeros(max(self.V, 1), np.int32)[:self.V].copy()
+        cnt = np.zeros(self.V, np.int32)
         avg, st = C.c_float(0), Stats()
         _ck(lib().gmx_avg_teen_cnt(self._h, age.ctypes.data if self.V else None, int(K), cnt.ctypes.data if self.V else None,
                                    C.byref(avg), C.byref(st)))
@@ -345,14 +345,14 @@ class Graph:
     def edge_order(self):
         """e_idx2idx after an upload with GMX_GRAPH_SORT_ROWS: uploaded slot of every slot of the sorted rows;
         None when the upload was already in order (identity)."""
-        out = np.zeros(max(self.E, 1), np.int32)[:self.E].copy()
+        out = np.zeros(self.E, np.int32)
         ident = C.c_int(1)
         _ck(lib().gmx_graph_edge_order(self._h, out.ctypes.data if self.E else None, C.byref(ident)))
         return None if ident.value else out
 
     def reverse_edge_map(self):
         """e_rev2idx: forward slot mirrored by each reverse-CSR slot."""
-        out = np.zeros(max(self.E, 1), np.int32)[:self.E].copy()
+        out = np.zeros(self.E, np.int32)
         _ck(lib().gmx_graph_reverse_edge_map(self._h, out.ctypes.data))
         return out
 
@@ -428,7 +428,7 @@ class BfsState:
         return n.value
 
     def download(self):
-        out = np.zeros(max(self.graph.V, 1), np.int32)[:self.graph.V].copy()
+        out = np.zeros(self.graph.V, np.int32)
         st = Stats()
         _ck(lib().gmx_bfs_download(self._h, out.ctypes.data, C.byref(st)))
         return out, st.as_dict()
@@ -662,7 +662,7 @@ class PageRankState:
         V = self.graph.V
         dt = np.float32 if self.elem == 4 else np.float64
         if out is None:
-            out = np.zeros(max(V, 1), dt)[:V].copy()
+            out = np.zeros(V, dt)
         _ck(lib().gmx_pr_download(self._h, out.ctypes.data))
         return out
 
