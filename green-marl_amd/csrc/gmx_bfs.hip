@@ -850,14 +850,23 @@ __global__ void bfs_apply_found_kernel(const unsigned long long* __restrict__ fo
     if ((threadIdx.x & 63) == 0) bfs_count(ctr, 0, cnt);
 }
 
+static int64_t bfs_hub_min_v() {
+    const char* e = getenv("GMX_BFS_HUB_MIN_V");
+    const long long v = e ? atoll(e) : 0;
+    return v > 0 ? (int64_t) v : BFS_HUB_MIN_V;
+}
+
 // The per-graph preprocessing of the bottom-up levels: the hub list (BFS_HUBS vertices with most out-edges) and hint[].
 static int bfs_build_hints(gmx_graph* g) {
     const int64_t V = g->V;
     GMX_CHECK(g->bfs_hint.alloc((size_t) (V ? V : 1)));
-    g->bfs_hint_plain = V > (int64_t) BFS_H_MASK;
+    // development / test options: GMX_BFS_PLAIN_HINTS=1 forces the plain encoding, GMX_BFS_HUB_MIN_V=<n> moves the size from
+    // which graphs get a hub list (and levels the LDS copy) -- so that every form can be run on small graphs
+    g->bfs_hint_plain = V > (int64_t) BFS_H_MASK || getenv("GMX_BFS_PLAIN_HINTS") != nullptr;
+    const int64_t hub_min_v = bfs_hub_min_v();
     // hubs only where a bottom-up level is long enough to gain from them: below 2^25 vertices the extra launch per level
     // (the hubs' bits) cost more than the probes it saved (RMAT-20/22/24: 5-10 % slower with hubs, RMAT-26: 10 % faster)
-    g->bfs_hubs = !g->bfs_hint_plain && V >= BFS_HUB_MIN_V ? BFS_HUBS : 0;
+    g->bfs_hubs = !g->bfs_hint_plain && V >= hub_min_v && V > BFS_HUBS ? BFS_HUBS : 0;
     if (V == 0) return GMX_OK;
     gmx_ws_scope scope;   // (temporaries from the workspace: see gmx_internal.h)
     wbuf<int32_t> slot_of;
@@ -1046,7 +1055,7 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
         // The LDS copy (16 KiB per workgroup, filled once by each of one resident set of workgroups) pays where the level is
         // long: the first bottom-up level of a run over at least 2^25 vertices (RMAT-26: 450 -> 323 us; the later levels, with
         // a fifth of the vertices still looking, were slower with it).  Otherwise the same 16 KiB are probed in memory.
-        const bool use_lds = hub_words > 0 && !b->cand_valid && v_hi - v_lo >= BFS_HUB_MIN_V;
+        const bool use_lds = hub_words > 0 && !b->cand_valid && v_hi - v_lo >= bfs_hub_min_v();
         hipLaunchKernelGGL(bfs_bottomup_part_kernel, dim3(grid_for((v_hi - v_lo + 3) / 4, BFS_THREADS, use_lds ? 256 * 7 : 256 * 32)), dim3(BFS_THREADS), 0, 0,
                            g->r_begin.p, g->r_node_idx.p, v_lo, v_hi, V, (const uint32_t*) b->bm[b->fr].p,
                            (const int32_t*) b->dist.p, b->bm[1 - b->fr].p, b->nranks == 1 ? b->dist.p : nullptr, b->level + 1, b->ctr.p,

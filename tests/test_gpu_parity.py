@@ -243,6 +243,33 @@ def test_hop_dist_direction_switches_twice(gmx):
         assert exchanges >= 3                           # bottom-up levels (one exchange each) in BOTH clusters
 
 
+@pytest.mark.parametrize("mode", ["plain", "hubs_lds", "hubs_memory"])
+def test_hop_dist_hint_encodings(gmx, mode, monkeypatch):
+    """The bottom-up levels' hint encodings on graphs small enough for the CPU: plain vertex ids (what a graph of more than
+    2^30 vertices gets), hub slots probed in the workgroups' LDS copy (graphs of 2^25 vertices and more: first bottom-up
+    level), hub slots probed in memory (their later levels; here: ranges shorter than the threshold, i.e. rank states).
+    The options are read when a graph's hints are built and when a level is launched."""
+    if mode == "plain":
+        monkeypatch.setenv("GMX_BFS_PLAIN_HINTS", "1")
+    else:
+        monkeypatch.setenv("GMX_BFS_HUB_MIN_V", str(1 << 17) if mode == "hubs_lds" else str(1 << 18))
+    for scale, permute in [(18, False), (18, True)]:
+        og = po.rmat_graph(scale, permute=permute)
+        g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+        hub = int(np.argmax(np.diff(og.begin)))
+        for root in (0, hub, og.N - 1):
+            want = po.bfs_queue(og, root)
+            dist, st = g.hop_dist(root)
+            assert np.array_equal(dist, want), (mode, scale, permute, root)
+        g.free()
+        # rank states: ranges of V / 2 and V / 3 vertices (below the LDS threshold of "hubs_memory", above it for "hubs_lds" / 2)
+        want = po.bfs_queue(og, hub)
+        for nranks in (2, 3):
+            outs, _, exchanges = _bfs_ranks_in_one_process(gmx, og, hub, nranks)
+            assert all(np.array_equal(o, want) for o in outs), (mode, nranks)
+            assert exchanges >= 1
+
+
 def test_hop_dist_bad_root(gmx, golden):
     c = golden["cases"]["rmat6_noperm"]
     g = gmx.Graph.upload(c["begin"], c["node_idx"], c["r_begin"], c["r_node_idx"])
