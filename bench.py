@@ -35,11 +35,17 @@ sys.path.insert(0, os.path.join(ROOT, "green-marl_amd"))
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+# the sources of the kernels of one PageRank step (the bench line's roofline kernels) and of the plan they run on
+STEP_SOURCES = ("gmx_pagerank.hip", "gmx_pr_cold.hip")
+
+
 def kernel_code_hash():
-    """sha256 over the HIP sources: a PMC traffic figure is only quoted for the code it was measured on."""
+    """sha256 over the HIP sources of the PageRank step: a PMC traffic figure is only quoted for the code it was measured
+    on (the other translation units -- traversal, triangle counting, graph construction -- do not run in the timed step)."""
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "green-marl_amd", "csrc", "*"))):
-        h.update(os.path.basename(f).encode())
+    for name in STEP_SOURCES:
+        f = os.path.join(ROOT, "green-marl_amd", "csrc", name)
+        h.update(name.encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
