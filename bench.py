@@ -190,13 +190,23 @@ def main():
     from dist_pagerank import DistPageRank, GmxEngine
 
     gmx.require_device()                       # no CPU fallback: fail loudly without the HIP path
+    # GMX_BENCH_SHARED_GPU=1 (development, a one-GPU box): every rank on device 0, the host-side process group (gloo) and
+    # the host barrier -- hipIpc works between processes sharing a device, RCCL does not.  It rehearses this file's
+    # N > 1 code (warm-up agreement, timing, exchange check, fallbacks, the JSON line); its numbers mean nothing.
+    shared_gpu = os.environ.get("GMX_BENCH_SHARED_GPU") == "1" and world > 1
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     gmx.set_device(local_rank)
     # GMX_BENCH_FORCE_COLLECTIVES=1 (development): run the RCCL calls with a single rank too
     force_coll = os.environ.get("GMX_BENCH_FORCE_COLLECTIVES") == "1" and "MASTER_PORT" in os.environ
     if world > 1 or force_coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    coll_dev = "cpu" if shared_gpu else "cuda"   # where this file's own small collectives live
 
     elem = 4 if args.dtype == "f32" else 8
     options = gmx.default_pr_options(1 << args.scale, world) if args.options < 0 else args.options
@@ -211,6 +221,7 @@ def main():
         # (most of the sweep) are reduced
         chunks = engine.set_chunks(args.chunks if args.chunks > 0 else 2)
     pr = DistPageRank(engine, always_exchange=force_coll, exchange=args.exchange if world > 1 else "collective",
+                      barrier="host" if shared_gpu else "collective",
                       pipeline=os.environ.get("GMX_BENCH_PIPELINE", "1") != "0")
     pr.reset(0.85)
     torch.cuda.synchronize()
@@ -220,7 +231,7 @@ def main():
         """True if `flag` holds on every rank."""
         if world == 1:
             return bool(flag)
-        t = torch.tensor([1.0 if flag else 0.0], device="cuda")
+        t = torch.tensor([1.0 if flag else 0.0], device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return float(t.item()) == 1.0
 
@@ -297,7 +308,7 @@ def main():
     exchange_check = None if verdict is None else "replicas equal an all-gather of the owned slices on every rank"
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt * 1e3 / args.steps
@@ -349,7 +360,9 @@ def main():
                        "step_form": "single rank" if world == 1 and not force_coll else
                                     (("pushed, pipelined" if pipelined else "pushed, plain") if pr.exchange == "push" else "collective")
                                     + (" (fell back from the pipelined form)" if fell_back else ""),
-                       "options": options, "setup_s": round(setup_s, 2), "last_diff": last_diff},
+                       "options": options, "setup_s": round(setup_s, 2), "last_diff": last_diff,
+                       **({"rehearsal": "GMX_BENCH_SHARED_GPU=1: all ranks on ONE GPU, host-side process group and barrier -- "
+                                        "this line exercises the N > 1 code, its numbers are not a measurement"} if shared_gpu else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          # the bytes the kernels really move (PMC) over the same time: the honest bandwidth figure next to

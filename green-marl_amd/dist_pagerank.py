@@ -260,10 +260,12 @@ class DistPageRank:
         eng.step_gather(0)
         self._wait_early()
         self._unpack(0)                    # (packed push) the tail chunk of the previous step, landed by now
+        self._tail_pending = False
         eng.step_gather(1)
         eng.step_chunk(0)
         eng.push_chunk(0)
         self._early_barrier(0)
+        self._tail_pending = True          # pushed, not yet unpacked: the next step's start or drain() does that
         eng.step_chunk(1)
         eng.push_chunk(1)
         if self.barrier == "host":
@@ -277,7 +279,9 @@ class DistPageRank:
         """Everything issued so far (incl. the travelling tail chunk) ordered before what this stream does next."""
         if self._early_work is not None:
             self._wait_early()
+        if getattr(self, "_tail_pending", False):   # (with the host barrier there is no pending collective to tell)
             self._unpack(0)
+            self._tail_pending = False
 
     def _step_pushed(self, chunks):
         eng = self.engine

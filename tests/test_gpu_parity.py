@@ -1291,3 +1291,33 @@ def test_pagerank_damping_outside_unit_interval(gmx):
             assert stt["iterations"] == it
             assert float(np.max(np.abs(rank.astype(np.float64) - want))) < tol * float(np.max(np.abs(want))), (d, dt)
     g.free()
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_bench_multi_rank_rehearsal(nranks):
+    """bench.py --gpus N as the driver launches it (torch.distributed.run, one process per rank), with the ranks sharing
+    this box's one GPU (GMX_BENCH_SHARED_GPU=1: gloo + host barrier instead of RCCL; the peer pushes go through hipIpc as
+    on a real node).  What it proves is this file's N > 1 code path end to end: warm-up agreement, the pipelined pushed
+    step, the replica check after the timed steps (no fallback), one JSON line from rank 0."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, GMX_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--scale", "22",
+                        "--steps", "4", "--warmup", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == nranks and out["steps"] == 4 and out["value"] > 0
+    cfg = out["config"]
+    assert cfg["exchange_check"] == "replicas equal an all-gather of the owned slices on every rank"
+    assert cfg["step_form"] == "pushed, pipelined", cfg["step_form"]      # no fallback
+    assert cfg["exchange_packed"] is True and cfg["exchange_bytes_per_rank_and_step"] > 0
+    assert "rehearsal" in cfg
