@@ -276,7 +276,8 @@ tc_oriented_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict_
                     // per probe, but 8 KiB per wave: 20 waves per CU instead of 32 -> 593 ms), every edge handled at the end
                     // with the longer list (0.44 TB fetched, 308 ms), the kilobyte of a step as one 16-byte load per lane instead of four
                     // 4-byte ones (what halved hop_dist's bottom-up levels: 275 ms here -- the lists are short, and four entries
-                    // per lane leave most lanes without a search).  What limits it is the rate at which the memory system
+                    // per lane leave most lanes without a search), the neighbour's two row-header words as one 8-byte gather from a
+                    // packed {first upper neighbour, row end} array instead of two 4-byte gathers (286 ms).  What limits it is the rate at which the memory system
                     // delivers these scattered 0.25-2.5 KB list reads, not the wave's own latency chain.
                     for (int32_t p = sbb + lane; p < sbe; p += TCO_PIECES * 64) {
                         int32_t w[TCO_PIECES];
