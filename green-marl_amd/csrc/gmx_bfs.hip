@@ -289,6 +289,71 @@ bfs_topdown_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict_
     for (unsigned int i = tid; i < nwin; i += BFS_THREADS) next_q[s_base + i] = s_win[i];
 }
 
+// A SPARSE frontier (about one out-edge per vertex: the tail levels of a traversal): one vertex per lane, no degree pass,
+// no scan, no merge-path.  RMAT-26's fifth level (36.5 K vertices, 36.0 K edges) cost 4 + ~45 (library scan) + 22 us of
+// kernels and launches for what is one round of gathers.  A lane walks up to BFS_SPARSE_OWN edges itself; what is left of
+// a longer row is taken by the whole wave afterwards, 64 edges per step, so no lane is ever alone with a hub.
+#define BFS_SPARSE_OWN 16
+__device__ __forceinline__ void bfs_sparse_visit(bool on, int32_t s, int32_t level, int32_t* __restrict__ dist, const int32_t* __restrict__ begin,
+                                                 int32_t* __restrict__ next_q, bfs_counters* __restrict__ ctr, int lane,
+                                                 unsigned long long& deg) {
+    bool won = false;
+    if (on && dist[s] == INT_MAX) won = atomicMin(&dist[s], level + 1) == INT_MAX;
+    const unsigned long long mw = __ballot(won);
+    if (mw) {   // (the lanes that are here together claim together)
+        const int leader = __ffsll((long long) mw) - 1;
+        unsigned long long at = 0;
+        if (lane == leader) at = atomicAdd(&ctr->next_count, (unsigned long long) __popcll(mw));
+        at = __shfl(at, leader, 64);
+        if (won) {
+            next_q[at + __popcll(mw & ((1ULL << lane) - 1))] = s;
+            deg += (unsigned long long) (begin[s + 1] - begin[s]);
+        }
+    }
+}
+__global__ void __launch_bounds__(BFS_THREADS)
+bfs_topdown_sparse_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx, const int32_t* __restrict__ cur_q,
+                          int64_t n, int32_t level, int32_t* __restrict__ dist, int32_t* __restrict__ next_q, bfs_counters* __restrict__ ctr) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    unsigned long long inspected = 0, deg = 0;
+    int32_t b = 0, e = 0;
+    if (i < n) {
+        const int32_t v = cur_q[i];
+        b = begin[v];
+        e = begin[v + 1];
+    }
+    const int32_t own_e = e - b > BFS_SPARSE_OWN ? b + BFS_SPARSE_OWN : e;
+    // (the loop runs while ANY lane of the wave has an edge left, so that the winners' ballots see whole waves)
+    for (int32_t k = 0; __ballot(b + k < own_e) != 0ull; k++) {
+        const bool on = b + k < own_e;
+        const int32_t s = on ? node_idx[b + k] : 0;
+        inspected += on;
+        bfs_sparse_visit(on, s, level, dist, begin, next_q, ctr, lane, deg);
+    }
+    unsigned long long pending = __ballot(own_e < e);
+    while (pending) {
+        const int src = __ffsll((long long) pending) - 1;
+        pending &= pending - 1;
+        const int32_t rb = __shfl(own_e, src, 64), re = __shfl(e, src, 64);
+        for (int32_t x0 = rb; x0 < re; x0 += 64) {
+            const bool on = x0 + lane < re;
+            const int32_t s = on ? node_idx[x0 + lane] : 0;
+            inspected += on;
+            bfs_sparse_visit(on, s, level, dist, begin, next_q, ctr, lane, deg);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        inspected += __shfl_down(inspected, o, 64);
+        deg += __shfl_down(deg, o, 64);
+    }
+    if (lane == 0) {
+        bfs_count(ctr, inspected, 0);
+        if (deg) atomicAdd(&ctr->next_edges, deg);
+    }
+}
+
 // The level out of the ROOT (every traversal's first): one row, nobody else visited.  Its distinct entries (the rows are
 // sorted: a repeated edge sits next to its copy) other than the root itself all get level + 1 -- no look at dist[], no
 // atomicMin: the general kernel spent 75-84 us on the 0.98 M out-edges of RMAT-26's vertex 0, four dependent random accesses
@@ -1101,6 +1166,18 @@ extern "C" int gmx_bfs_step_begin(gmx_bfs_t* b, int* needs_exchange) {
                 b->bm_clean[b->fr] = false;
                 b->first_bm_level = 1;
             }
+            int32_t* t = b->cur_q;
+            b->cur_q = b->next_q;
+            b->next_q = t;
+            b->cur_edges = -2;
+            GMX_HIP(hipGetLastError());
+            return GMX_OK;
+        }
+        if (!have_off && b->cur_count <= (1 << 20) && m_f <= 2 * b->cur_count + 1024) {   // a sparse frontier: one vertex per lane
+            GMX_HIP(hipMemsetAsync(&b->ctr.p->next_count, 0, 2 * sizeof(unsigned long long), 0));
+            hipLaunchKernelGGL(bfs_topdown_sparse_kernel, dim3(grid_for(b->cur_count, BFS_THREADS, 1 << 20)), dim3(BFS_THREADS), 0, 0,
+                               (const int32_t*) g->begin.p, (const int32_t*) g->node_idx.p, (const int32_t*) b->cur_q, b->cur_count, b->level,
+                               b->dist.p, b->next_q, b->ctr.p);
             int32_t* t = b->cur_q;
             b->cur_q = b->next_q;
             b->next_q = t;
