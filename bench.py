@@ -149,7 +149,7 @@ def extras(gmx, graph26, scale):
                 "gmx_hop_dist calls incl. the 256 MB dist[] download, the first one also the per-graph bottom-up hint and traversal "
                 "state; TEPS in the Graph500 convention (out-edges of the reached vertices / time); algorithmic bytes 8 E_r + 12 V_r -- "
                 "direction optimisation examines fewer edges, so this fraction is a work-skipping figure, not bandwidth (measured "
-                "traffic: profiles/round3_c_bfs_rmat26_pmc.txt)"}
+                "traffic: profiles/round3_d_bfs_rmat26_pmc.txt)"}
     gb.free()
     return out
 
