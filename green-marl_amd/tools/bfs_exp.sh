@@ -14,7 +14,7 @@ print("hop_dist %.3f ms levels %d reached %d examined %d" % (s["kernel_ms"], s["
 PY
 for v in "$@"; do
   export $var=$v
-  d=gpurun_out/bfsexp_${var}_$v
+  d=gpurun_out/bfsexp_${var}_$(echo "$v" | tr '/.' '__')
   rm -rf $d
   rocprofv3 --kernel-trace --output-format csv -d $d -- python3 /tmp/bfs_one.py > $d.log 2>&1 || { tail -5 $d.log; exit 1; }
   echo "== $var=$v: $(grep hop_dist $d.log)"
