@@ -190,6 +190,28 @@ def test_reference_dataset_kats(gmx, name):
         assert m and int(m.group(1)) == KAT_TC[name]
 
 
+def test_hop_dist_rmat24_other_roots_exact(gmx):
+    """RMAT-24 from roots that are NOT hubs -- a leaf-like vertex, random reachable vertices, the last vertex: the first
+    levels are sparse top-down levels (one vertex per lane), the level out of the root is tiny (no bitmap written there),
+    the switch to bottom-up comes later and from a queue.  dist[] bit-exact against the sequential queue BFS."""
+    import pyoracle as po
+    scale = 24
+    N, M = 1 << scale, 16 << scale
+    g = gmx.Graph.rmat(N, M, 1997, 0.57, 0.19, 0.19, True)
+    begin, node_idx, rb, rn = g.download()
+    og = po.Graph(N, begin, node_idx, rb, rn)
+    outdeg = np.diff(begin)
+    rng = np.random.default_rng(24)
+    roots = [int(np.flatnonzero(outdeg == 1)[0]), int(np.flatnonzero(outdeg == 2)[7]), N - 1]
+    roots += [int(r) for r in rng.choice(np.flatnonzero(outdeg >= 3), 2, replace=False)]
+    for root in roots:
+        want = po.bfs_queue(og, root)
+        dist, st = g.hop_dist(root)
+        assert np.array_equal(dist, want), root
+        assert st["vertices_reached"] == int((want != INT_MAX).sum())
+    g.free()
+
+
 @pytest.mark.parametrize("scale,permute", [(24, False), (26, False), (26, True)])
 def test_hop_dist_full_size_properties(gmx, scale, permute):
     """BASELINE configs[2] (BFS from vertex 0 on RMAT-26).  dist is the BFS depth iff: dist[root]=0;
