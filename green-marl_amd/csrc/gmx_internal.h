@@ -126,6 +126,10 @@ struct gmx_graph {
     // forward CSR of the same graph renumbered by ascending degree (its reverse CSR is the same arrays)
     int tc_sym_state = -1;
     gmx_graph* tc_oriented = nullptr;
+    // on the oriented copy: the adjacency among its tc_hubs highest vertices (the hubs: ids >= V - tc_hubs) as a bit matrix,
+    // row u - (V - tc_hubs), bit w - (V - tc_hubs) (gmx_tc.hip)
+    dbuf<uint32_t> tc_hub_bits;
+    int64_t tc_hubs = 0;
     // hop_dist: the single-rank traversal state (queues, bitmaps, dist[]) of the whole-kernel entry, kept for the
     // next call on the same graph instead of nine allocations per call
     gmx_bfs* bfs_cache = nullptr;

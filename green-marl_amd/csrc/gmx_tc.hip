@@ -167,6 +167,8 @@ tc_forward_only_kernel(const int32_t* __restrict__ begin, const int32_t* __restr
 #define TCO_ALONE 4     // a lane walks a side of up to this many entries by itself (measured flat from 0 to 8; 48: +25 %)
 #define TCO_RATIO 4     // stream Up(u) and search the staged tail while |Up(u)| <= TCO_RATIO * |tail| (2: +15 %, 16: +7 %)
 #define TCO_PIECES 4    // 256-byte pieces of Up(u) a wave keeps in flight
+#define TCO_HUB_TAIL 4 // against a hub u the tail of Up(v) is the side to walk while it is at most this many times |Up(u)|
+#define TCO_HUB_MAX 131072   // hubs of the bit matrix (2 GiB at most)
 #define TCO_CAP 1024    // upper-list entries staged per wave (4 KiB; 4 waves: 16 KiB of LDS per workgroup, 8 workgroups per CU)
 
 __global__ void tc_up_begin_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx, int64_t V,
@@ -174,6 +176,25 @@ __global__ void tc_up_begin_kernel(const int32_t* __restrict__ begin, const int3
     int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t) gridDim.x * blockDim.x;
     for (; v < V; v += stride) up_begin[v] = tc_lower_bound(node_idx, begin[v], begin[v + 1], (int32_t) v + 1);
+}
+
+// The hubs' adjacency as bits.  On the degree-ordered copy the H highest ids are the H vertices of highest degree, and every
+// upper neighbour of a hub is a hub: Up(u) of hub u is row u of an H x H bit matrix.  "is w in Up(u)" is then ONE load
+// instead of a binary search over Up(u) in memory (~10 dependent loads on as many lines), and a slot whose u is a hub is
+// cheapest from the side of v's tail -- a few entries, the hubs above u -- however long Up(u) is.  (RMAT-20 symmetrised,
+// offline: 83 % of the oriented edges end in one of the V/64 highest vertices, and they carry 92 % of the entries the
+// kernel would otherwise stream or search.)  One wave per hub row.
+__global__ void tc_hub_bits_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx, const int32_t* __restrict__ up_begin,
+                                   int64_t base, int64_t H, uint32_t* __restrict__ bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t) blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= H) return;
+    const int64_t u = base + row;
+    uint32_t* dst = bits + row * (H >> 5);
+    for (int32_t p = up_begin[u] + lane; p < begin[u + 1]; p += 64) {
+        const int64_t w = node_idx[p] - base;   // > row
+        atomicOr(&dst[w >> 5], 1u << (w & 31));
+    }
 }
 
 __device__ __forceinline__ int32_t tco_lds_lower_bound(const int32_t* a, int32_t lo, int32_t hi, int32_t x) {
@@ -200,7 +221,8 @@ __global__ void tc_groups_kernel(const int32_t* __restrict__ begin, const int32_
 __global__ void __launch_bounds__(TCO_WAVES * 64)
 tc_oriented_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx, const int32_t* __restrict__ up_begin,
                    const int32_t* __restrict__ grp_off, int64_t V, int part, int nparts, int alone_max, int ratio,
-                   unsigned long long* __restrict__ next_claim, unsigned long long* __restrict__ total) {
+                   unsigned long long* __restrict__ next_claim, unsigned long long* __restrict__ total,
+                   const uint32_t* __restrict__ hub_bits, int64_t hub_base /* V: no hubs */, int hub_words /* per row */) {
     __shared__ int32_t s_up[TCO_WAVES][TCO_CAP];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -239,16 +261,26 @@ tc_oriented_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict_
             // that is cheaper to stream.
             const int32_t i = lane;
             const bool act = i + 1 < da;
-            int32_t bb = 0, be = 0;
+            int32_t bb = 0, be = 0, u = 0;
             if (act) {
-                const int32_t u = in_lds ? A[i] : node_idx[ab + i];
+                u = in_lds ? A[i] : node_idx[ab + i];
                 bb = up_begin[u];
                 be = begin[u + 1];
             }
             const int32_t db = be - bb, ta = act ? da - (i + 1) : 0;
-            const int32_t shorter = db < ta ? db : ta;
+            // the side to walk: the tail of Up(v) above u, or Up(u).  Against a hub u a tail entry costs one bit probe,
+            // so the tail is the side unless it is far the longer one
+            const bool hubu = act && u >= hub_base;
+            const bool tail_side = hubu ? ta <= TCO_HUB_TAIL * db : ta < db;
+            const uint32_t* hrow = hub_bits + (hubu ? (int64_t) (u - hub_base) * hub_words : 0);
+            const int32_t shorter = db == 0 || ta == 0 ? 0 : (tail_side ? ta : db);
             if (act && shorter > 0 && shorter <= alone_max) {
-                if (db <= ta) {
+                if (tail_side && hubu) {
+                    for (int32_t p = i + 1; p < da; p++) {
+                        const int64_t w = (in_lds ? A[p] : node_idx[ab + p]) - hub_base;
+                        c += (hrow[w >> 5] >> (w & 31)) & 1u;
+                    }
+                } else if (!tail_side) {
                     for (int32_t p = bb; p < be; p++) {
                         const int32_t w = node_idx[p];
                         if (in_lds) {
@@ -267,7 +299,14 @@ tc_oriented_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict_
                 m &= m - 1;
                 const int32_t sbb = __shfl(bb, src, 64), sbe = __shfl(be, src, 64);
                 const int32_t sdb = sbe - sbb, sta = da - (src + 1);
-                if (in_lds && sdb <= ratio * sta) {   // stream Up(u), search the staged tail
+                const int32_t su = __shfl(u, src, 64);
+                if (su >= hub_base && sta <= TCO_HUB_TAIL * sdb) {   // a hub: the lanes stride over the tail, one bit probe each
+                    const uint32_t* srow = hub_bits + (int64_t) (su - hub_base) * hub_words;
+                    for (int32_t p = src + 1 + lane; p < da; p += 64) {
+                        const int64_t w = (in_lds ? A[p] : node_idx[ab + p]) - hub_base;
+                        c += (srow[w >> 5] >> (w & 31)) & 1u;
+                    }
+                } else if (in_lds && sdb <= ratio * sta) {   // stream Up(u), search the staged tail
                     // TCO_PIECES 256-byte pieces of Up(u) in flight per wave before the searches start: with one piece per
                     // step the next load waited behind ten dependent LDS probes (282 -> 264 ms on symmetrised RMAT-24).
                     // Measured and not kept (profiles/round3_tc_*: the kernel fetches 0.68 TB per call at 2.4 TB/s with the
@@ -401,6 +440,23 @@ static int tc_counting_graph(gmx_graph* g, gmx_graph** out, bool* oriented) {
                 return st;
             }
             hipLaunchKernelGGL(tc_up_begin_kernel, dim3(tc_grid(g->V)), dim3(TC_THREADS), 0, s, o->begin.p, o->node_idx.p, g->V, o->r_begin.p);
+            // the hubs' adjacency as a bit matrix (GMX_TC_HUBS=<n> sets their number, 0 = none: development option)
+            {
+                int64_t H = g->V < TCO_HUB_MAX ? g->V : TCO_HUB_MAX;
+                if (const char* e = getenv("GMX_TC_HUBS")) H = atoll(e) < H ? atoll(e) : H;
+                H &= ~(int64_t) 63;
+                if (H > 0) {
+                    const size_t words = (size_t) H * (size_t) (H >> 5);
+                    if ((st = o->tc_hub_bits.alloc(words))) {
+                        delete o;
+                        return st;
+                    }
+                    GMX_HIP(hipMemsetAsync(o->tc_hub_bits.p, 0, words * sizeof(uint32_t), s));
+                    hipLaunchKernelGGL(tc_hub_bits_kernel, dim3((unsigned) ((H + 3) / 4)), dim3(256), 0, s, (const int32_t*) o->begin.p,
+                                       (const int32_t*) o->node_idx.p, (const int32_t*) o->r_begin.p, g->V - H, H, o->tc_hub_bits.p);
+                    o->tc_hubs = H;
+                }
+            }
             // work items of the staged-list kernel: exclusive scan of the 64-slot groups per vertex (kept in the
             // copy's otherwise unused r_node_idx)
             {
@@ -481,7 +537,7 @@ static int tc_count_part(gmx_graph_t* g, int part, int nparts, bool common_nbr_f
     if (oriented && tc_use_lds()) {
         hipLaunchKernelGGL(tc_oriented_kernel, dim3(256 * 8), dim3(TCO_WAVES * 64), 0, 0, g->begin.p, g->node_idx.p,
                            (const int32_t*) g->r_begin.p, (const int32_t*) g->r_node_idx.p, g->V, part, nparts,
-                           TCO_ALONE, TCO_RATIO, ctr.p + 1, ctr.p);
+                           TCO_ALONE, TCO_RATIO, ctr.p + 1, ctr.p, (const uint32_t*) g->tc_hub_bits.p, g->V - g->tc_hubs, (int) (g->tc_hubs >> 5));
         GMX_HIP(hipGetLastError());
     } else if (have_rows) {
         dbuf<tc_pair> big;
