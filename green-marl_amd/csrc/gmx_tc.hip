@@ -167,8 +167,8 @@ tc_forward_only_kernel(const int32_t* __restrict__ begin, const int32_t* __restr
 #define TCO_ALONE 4     // a lane walks a side of up to this many entries by itself (measured flat from 0 to 8; 48: +25 %)
 #define TCO_RATIO 4     // stream Up(u) and search the staged tail while |Up(u)| <= TCO_RATIO * |tail| (2: +15 %, 16: +7 %)
 #define TCO_PIECES 4    // 256-byte pieces of Up(u) a wave keeps in flight
-#define TCO_HUB_TAIL 4 // against a hub u the tail of Up(v) is the side to walk while it is at most this many times |Up(u)|
-#define TCO_HUB_MAX 131072   // hubs of the bit matrix (2 GiB at most)
+#define TCO_HUB_TAIL 4 // against a hub u the tail of Up(v) is the side to walk while it is at most this many times |Up(u)| (2 .. 64: the same; 1: +30 %)
+#define TCO_HUB_MAX 131072   // hubs of the bit matrix (2 GiB at most; half of that up to 2^24 vertices)
 #define TCO_CAP 1024    // upper-list entries staged per wave (4 KiB; 4 waves: 16 KiB of LDS per workgroup, 8 workgroups per CU)
 
 __global__ void tc_up_begin_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx, int64_t V,
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(TCO_WAVES * 64)
 tc_oriented_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx, const int32_t* __restrict__ up_begin,
                    const int32_t* __restrict__ grp_off, int64_t V, int part, int nparts, int alone_max, int ratio,
                    unsigned long long* __restrict__ next_claim, unsigned long long* __restrict__ total,
-                   const uint32_t* __restrict__ hub_bits, int64_t hub_base /* V: no hubs */, int hub_words /* per row */) {
+                   const uint32_t* __restrict__ hub_bits, int64_t hub_base /* V: no hubs */, int hub_words /* per row */, int hub_tail) {
     __shared__ int32_t s_up[TCO_WAVES][TCO_CAP];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -271,7 +271,7 @@ tc_oriented_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict_
             // the side to walk: the tail of Up(v) above u, or Up(u).  Against a hub u a tail entry costs one bit probe,
             // so the tail is the side unless it is far the longer one
             const bool hubu = act && u >= hub_base;
-            const bool tail_side = hubu ? ta <= TCO_HUB_TAIL * db : ta < db;
+            const bool tail_side = hubu ? ta <= hub_tail * db : ta < db;
             const uint32_t* hrow = hub_bits + (hubu ? (int64_t) (u - hub_base) * hub_words : 0);
             const int32_t shorter = db == 0 || ta == 0 ? 0 : (tail_side ? ta : db);
             if (act && shorter > 0 && shorter <= alone_max) {
@@ -300,7 +300,7 @@ tc_oriented_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict_
                 const int32_t sbb = __shfl(bb, src, 64), sbe = __shfl(be, src, 64);
                 const int32_t sdb = sbe - sbb, sta = da - (src + 1);
                 const int32_t su = __shfl(u, src, 64);
-                if (su >= hub_base && sta <= TCO_HUB_TAIL * sdb) {   // a hub: the lanes stride over the tail, one bit probe each
+                if (su >= hub_base && sta <= hub_tail * sdb) {   // a hub: the lanes stride over the tail, one bit probe each
                     const uint32_t* srow = hub_bits + (int64_t) (su - hub_base) * hub_words;
                     for (int32_t p = src + 1 + lane; p < da; p += 64) {
                         const int64_t w = (in_lds ? A[p] : node_idx[ab + p]) - hub_base;
@@ -442,8 +442,9 @@ static int tc_counting_graph(gmx_graph* g, gmx_graph** out, bool* oriented) {
             hipLaunchKernelGGL(tc_up_begin_kernel, dim3(tc_grid(g->V)), dim3(TC_THREADS), 0, s, o->begin.p, o->node_idx.p, g->V, o->r_begin.p);
             // the hubs' adjacency as a bit matrix (GMX_TC_HUBS=<n> sets their number, 0 = none: development option)
             {
-                int64_t H = g->V < TCO_HUB_MAX ? g->V : TCO_HUB_MAX;
-                if (const char* e = getenv("GMX_TC_HUBS")) H = atoll(e) < H ? atoll(e) : H;
+                int64_t H = g->V > (1LL << 24) ? TCO_HUB_MAX : TCO_HUB_MAX / 2;   // (RMAT-24: 65536 and 131072 hubs measured the same, 32768 +30 %)
+                if (H > g->V) H = g->V;
+                if (const char* e = getenv("GMX_TC_HUBS")) H = atoll(e) < g->V ? atoll(e) : g->V;
                 H &= ~(int64_t) 63;
                 if (H > 0) {
                     const size_t words = (size_t) H * (size_t) (H >> 5);
@@ -537,7 +538,8 @@ static int tc_count_part(gmx_graph_t* g, int part, int nparts, bool common_nbr_f
     if (oriented && tc_use_lds()) {
         hipLaunchKernelGGL(tc_oriented_kernel, dim3(256 * 8), dim3(TCO_WAVES * 64), 0, 0, g->begin.p, g->node_idx.p,
                            (const int32_t*) g->r_begin.p, (const int32_t*) g->r_node_idx.p, g->V, part, nparts,
-                           TCO_ALONE, TCO_RATIO, ctr.p + 1, ctr.p, (const uint32_t*) g->tc_hub_bits.p, g->V - g->tc_hubs, (int) (g->tc_hubs >> 5));
+                           getenv("GMX_TC_ALONE") ? atoi(getenv("GMX_TC_ALONE")) : TCO_ALONE, getenv("GMX_TC_RATIO") ? atoi(getenv("GMX_TC_RATIO")) : TCO_RATIO, ctr.p + 1, ctr.p, (const uint32_t*) g->tc_hub_bits.p, g->V - g->tc_hubs, (int) (g->tc_hubs >> 5),
+                           getenv("GMX_TC_HUB_TAIL") ? atoi(getenv("GMX_TC_HUB_TAIL")) : TCO_HUB_TAIL);
         GMX_HIP(hipGetLastError());
     } else if (have_rows) {
         dbuf<tc_pair> big;
