@@ -125,7 +125,7 @@ def extras(gmx, graph26, scale):
                                             "note": "BASELINE configs[4]; E = edge slots of the symmetrised graph; merge_form_* = SURVEY 8d's figure for the "
                                                     "sorted-merge form in the emitted vertex order (4 sum d^2) over the measured time -- the degree-ordered "
                                                     "kernel skips most of that work; its measured HBM traffic and unit utilisation: "
-                                                    "profiles/round3_tc_rmat24_pmc.txt"}
+                                                    "profiles/round3_d_tc_rmat24_pmc.txt"}
     assert T == T2
     gs.free()
     # hop_dist from vertex 0 on RMAT-26 without the final permutation (vertex 0 is then the top hub; with
