@@ -874,6 +874,26 @@ def test_triangle_counting_parts_add_up(gmx, nparts):
     g.free()
 
 
+@pytest.mark.parametrize("hubs", ["0", "64", "1024", "1000000"])
+def test_triangle_counting_hub_matrix_sizes(gmx, hubs, monkeypatch):
+    """The degree-ordered copy keeps the adjacency among its H highest vertices as a bit matrix (slots whose neighbour is a
+    hub are counted by bit probes from the tail's side): no hubs, a few, many, and every vertex a hub give the oracle's
+    count -- whole and dealt to three parts -- on RMAT graphs and on a clique (every list longer than the LDS slice)."""
+    monkeypatch.setenv("GMX_TC_HUBS", hubs)     # read when the copy is built
+    for scale in (10, 14, 16):
+        sym = po.symmetrize(po.rmat_graph(scale, permute=True))
+        g = gmx.Graph.upload(sym.begin, sym.node_idx, sym.r_begin, sym.r_node_idx)
+        want = po.triangle_counting(sym)
+        assert g.triangle_counting()[0] == want, (hubs, scale)
+        assert sum(g.triangle_counting(p, 3)[0] for p in range(3)) == want
+        g.free()
+    n = 1500
+    iu, ju = np.triu_indices(n, 1)
+    g = gmx.Graph.from_edges(n, np.concatenate([iu, ju]).astype(np.int32), np.concatenate([ju, iu]).astype(np.int32))
+    assert g.triangle_counting()[0] == n * (n - 1) * (n - 2) // 6
+    g.free()
+
+
 def test_triangle_counting_degree_oriented_path(gmx, monkeypatch):
     """Symmetric simple graphs are counted on a degree-ordered copy (T is numbering-independent there); the
     count must equal the emitted-order count and the oracle's.  Symmetric graphs WITH duplicate slots or
