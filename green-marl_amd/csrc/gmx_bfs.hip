@@ -1919,9 +1919,21 @@ __global__ void filtered_sum_kernel(const int32_t* __restrict__ prop, const int3
         s += __shfl_down(s, o, 64);
         c += __shfl_down(c, o, 64);
     }
+    // one pair of adds per workgroup (a pair per wave, all on one cache line, was 225 us of adds for a 20 us pass)
+    __shared__ unsigned long long s_s[BFS_THREADS / 64], s_c[BFS_THREADS / 64];
     if ((threadIdx.x & 63) == 0) {
-        if (s) atomicAdd(&out[0], s);
-        if (c) atomicAdd(&out[1], c);
+        s_s[threadIdx.x >> 6] = s;
+        s_c[threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long ts = 0, tc = 0;
+        for (int i = 0; i < (int) (blockDim.x >> 6); i++) {
+            ts += s_s[i];
+            tc += s_c[i];
+        }
+        if (ts) atomicAdd(&out[0], ts);
+        if (tc) atomicAdd(&out[1], tc);
     }
 }
 
@@ -2040,23 +2052,155 @@ row_count_long_kernel(const int32_t* __restrict__ begin, const int32_t* __restri
     if (total && lane == 0 && acc) atomicAdd(total, acc);
 }
 
-// rows (all, or those whose bit is set in row_bm) count their neighbours by the probe bitmap
-static int count_by_bitmap(const int32_t* begin, const int32_t* idx, int64_t V, const unsigned long long* row_bm,
+// The same count over the FLAT slot array (round 3): a workgroup takes ROWCNT_ITEMS consecutive items of the merged sequence
+// (row ends, slots) -- merge-path over begin[], as in the top-down BFS level -- so that the slots are read coalesced, eight per
+// thread and all in flight, whatever the rows look like; a slot finds its row by bisection in the LDS copy of the range's
+// begin[] and adds its bit to the row's LDS counter.  With one row per lane (above) every lane walked its own list: 4-byte
+// loads, one 64-byte request each -- RMAT-24: avg_teen_cnt 6.1 ms, conduct 5.0 ms for 1 GB of slots.
+#define ROWCNT_ITEMS 2048
+// rows consumed at the diagonals k * ROWCNT_ITEMS, k = 0 .. nb: one thread per diagonal.  (Searched by the workgroups
+// themselves -- two threads, 24 dependent loads over begin[], everybody else at the barrier -- this was 19 of the ~27 us a
+// workgroup took.)
+__global__ void row_count_split_kernel(const int32_t* __restrict__ begin, int64_t V, int64_t E, int64_t nb, int64_t* __restrict__ split) {
+    const int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > nb) return;
+    int64_t dk = k * ROWCNT_ITEMS;
+    if (dk > V + E) dk = V + E;
+    int64_t lo = dk > E ? dk - E : 0, hi = dk < V ? dk : V;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t) begin[mid + 1] <= dk - mid - 1) lo = mid + 1; else hi = mid;
+    }
+    split[k] = lo;
+}
+
+__global__ void __launch_bounds__(BFS_THREADS)
+row_count_flat_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ idx, int64_t V, int64_t E, const int64_t* __restrict__ split,
+                      const uint32_t* __restrict__ row_bm, const uint32_t* __restrict__ probe_bm, int invert,
+                      int32_t* __restrict__ cnt /* zeroed */, unsigned long long* __restrict__ total) {
+    __shared__ int32_t s_off[ROWCNT_ITEMS + 2];
+    __shared__ int32_t s_cnt[ROWCNT_ITEMS + 2];
+    const int tid = threadIdx.x;
+    // merge-path split of the diagonals k * ITEMS and (k + 1) * ITEMS: (rows consumed, slots consumed)
+    int64_t d0 = (int64_t) blockIdx.x * ROWCNT_ITEMS, d1 = d0 + ROWCNT_ITEMS;
+    if (d1 > V + E) d1 = V + E;
+    const int64_t v0 = split[blockIdx.x], v1 = split[blockIdx.x + 1], e0 = d0 - v0, e1 = d1 - v1;
+    const int nv = (int) (v1 - v0) + 1;   // rows touched: v0 .. v1 (the last one may be partial, or == V)
+    for (int i = tid; i < nv; i += BFS_THREADS) {
+        const int64_t vi = v0 + i;
+        s_off[i] = vi <= V ? begin[vi < V ? vi : V] : (int32_t) E;
+        // (the row's own bit, asked once per row, rides in the counter's sign: -1 = this row counts nothing)
+        s_cnt[i] = row_bm && vi < V && !((row_bm[vi >> 5] >> (vi & 31)) & 1u) ? -1 : 0;
+    }
+    if (tid == 0) s_off[nv] = INT_MAX;   // sentinel
+    __syncthreads();
+    if (e1 > e0) {   // (workgroup-uniform)
+        constexpr int K = ROWCNT_ITEMS / BFS_THREADS;
+        const int lane = tid & 63;
+        int32_t w[K], row[K];
+        bool on[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int64_t x = e0 + tid + (int64_t) k * BFS_THREADS;
+            on[k] = x < e1;
+            const int64_t xc = on[k] ? x : e0;
+            int lo = 0, hi = nv - 1;     // row of slot x: last i with s_off[i] <= x
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if ((int64_t) s_off[mid] <= xc) lo = mid; else hi = mid - 1;
+            }
+            row[k] = lo;
+            on[k] = on[k] && s_cnt[lo] >= 0;   // (nobody adds to a row that counts nothing, so the sign stays)
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) w[k] = on[k] ? idx[e0 + tid + (int64_t) k * BFS_THREADS] : 0;   // (unasked rows' slots are not read)
+        uint32_t pw[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) pw[k] = probe_bm[w[k] >> 5];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            // consecutive lanes hold consecutive slots: the lanes of one row are a run, and the run's first lane adds the
+            // run's count -- one LDS add per (row, wave, pass) instead of one per slot on the same word
+            const bool bit = on[k] && ((((pw[k] >> (w[k] & 31)) & 1u) != 0) != (invert != 0));
+            const unsigned long long m = __ballot(bit);
+            const int prev = __shfl_up(row[k], 1, 64);
+            const unsigned long long heads = __ballot(lane == 0 || prev != row[k]);
+            if (m && ((heads >> lane) & 1ull)) {
+                const unsigned long long after = lane == 63 ? 0ull : heads >> (lane + 1);
+                const int len = after ? __ffsll((long long) after) : 64 - lane;   // lanes of this run
+                const unsigned long long mask = (len == 64 ? ~0ull : ((1ull << len) - 1ull)) << lane;
+                const int c = __popcll(m & mask);
+                if (c) atomicAdd(&s_cnt[row[k]], c);
+            }
+        }
+    }
+    __syncthreads();
+    unsigned long long acc = 0;
+    for (int i = tid; i < nv; i += BFS_THREADS) {
+        const int32_t c = s_cnt[i];
+        if (c <= 0) continue;
+        acc += (unsigned long long) c;
+        if (cnt) {
+            const int64_t r = v0 + i;
+            // a row whose slots all lie in this workgroup's range is written; the (at most two) rows cut by the range add
+            const bool whole = (int64_t) s_off[i] >= e0 && i + 1 < nv && (int64_t) s_off[i + 1] <= e1;
+            if (whole) cnt[r] = c; else atomicAdd(&cnt[r], c);
+        }
+    }
+    if (total) {   // one add per workgroup, on one of 64 words (131 K workgroups adding to ONE word: ~90 adds per us, 3.7 ms)
+        __shared__ unsigned long long s_red[BFS_THREADS / 64];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if ((tid & 63) == 0) s_red[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long t = 0;
+            for (int i = 0; i < BFS_THREADS / 64; i++) t += s_red[i];
+            if (t) atomicAdd(&total[blockIdx.x & 63], t);
+        }
+    }
+}
+__global__ void sum_shards_kernel(const unsigned long long* __restrict__ shard, unsigned long long* __restrict__ total) {
+    unsigned long long t = shard[threadIdx.x];   // 64 threads
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+    if (threadIdx.x == 0 && t) atomicAdd(total, t);
+}
+
+// rows (all, or those whose bit is set in row_bm) count their neighbours by the probe bitmap; cnt (if given) is zeroed by the caller
+static int count_by_bitmap(const int32_t* begin, const int32_t* idx, int64_t V, int64_t E, const unsigned long long* row_bm,
                            const unsigned long long* probe_bm, int invert, int32_t* cnt, unsigned long long* total) {
-    dbuf<int32_t> long_rows;
-    dbuf<unsigned long long> nlong;
-    GMX_CHECK(long_rows.alloc((size_t) V));
-    GMX_CHECK(nlong.alloc(1));
-    GMX_HIP(hipMemsetAsync(nlong.p, 0, sizeof(unsigned long long), 0));
-    hipLaunchKernelGGL(row_count_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 32)), dim3(BFS_THREADS), 0, 0, begin, idx, V,
-                       (const uint32_t*) row_bm, (const uint32_t*) probe_bm, invert, cnt, long_rows.p, nlong.p, total);
-    unsigned long long h = 0;
-    GMX_HIP(hipMemcpy(&h, nlong.p, sizeof(h), hipMemcpyDeviceToHost));
-    if (h) {
-        int64_t wb = (int64_t) ((h * 64 + BFS_THREADS - 1) / BFS_THREADS);
-        if (wb > 256 * 32) wb = 256 * 32;
-        hipLaunchKernelGGL(row_count_long_kernel, dim3((unsigned) wb), dim3(BFS_THREADS), 0, 0, begin, idx, (const int32_t*) long_rows.p, h,
-                           (const uint32_t*) probe_bm, invert, cnt, total);
+    if (getenv("GMX_ROWCNT_PER_ROW")) {   // development option: the one-row-per-lane form
+        dbuf<int32_t> long_rows;
+        dbuf<unsigned long long> nlong;
+        GMX_CHECK(long_rows.alloc((size_t) V));
+        GMX_CHECK(nlong.alloc(1));
+        GMX_HIP(hipMemsetAsync(nlong.p, 0, sizeof(unsigned long long), 0));
+        hipLaunchKernelGGL(row_count_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 32)), dim3(BFS_THREADS), 0, 0, begin, idx, V,
+                           (const uint32_t*) row_bm, (const uint32_t*) probe_bm, invert, cnt, long_rows.p, nlong.p, total);
+        unsigned long long h = 0;
+        GMX_HIP(hipMemcpy(&h, nlong.p, sizeof(h), hipMemcpyDeviceToHost));
+        if (h) {
+            int64_t wb = (int64_t) ((h * 64 + BFS_THREADS - 1) / BFS_THREADS);
+            if (wb > 256 * 32) wb = 256 * 32;
+            hipLaunchKernelGGL(row_count_long_kernel, dim3((unsigned) wb), dim3(BFS_THREADS), 0, 0, begin, idx, (const int32_t*) long_rows.p, h,
+                               (const uint32_t*) probe_bm, invert, cnt, total);
+        }
+        GMX_HIP(hipGetLastError());
+        return GMX_OK;
+    }
+    const int64_t nb = (V + E + ROWCNT_ITEMS - 1) / ROWCNT_ITEMS;
+    if (nb > 0) {
+        dbuf<int64_t> split;
+        dbuf<unsigned long long> shard;
+        GMX_CHECK(split.alloc((size_t) nb + 1));
+        GMX_CHECK(shard.alloc(64));
+        GMX_HIP(hipMemsetAsync(shard.p, 0, 64 * sizeof(unsigned long long), 0));
+        hipLaunchKernelGGL(row_count_split_kernel, dim3((unsigned) ((nb + 1 + BFS_THREADS - 1) / BFS_THREADS)), dim3(BFS_THREADS), 0, 0, begin, V, E, nb, split.p);
+        hipLaunchKernelGGL(row_count_flat_kernel, dim3((unsigned) nb), dim3(BFS_THREADS), 0, 0, begin, idx, V, E, (const int64_t*) split.p,
+                           (const uint32_t*) row_bm, (const uint32_t*) probe_bm, invert, cnt, total ? shard.p : nullptr);
+        if (total) hipLaunchKernelGGL(sum_shards_kernel, dim3(1), dim3(64), 0, 0, (const unsigned long long*) shard.p, total);
+        GMX_HIP(hipDeviceSynchronize());   // (split and shard are released here)
     }
     GMX_HIP(hipGetLastError());
     return GMX_OK;
@@ -2089,7 +2233,7 @@ extern "C" int gmx_avg_teen_cnt(gmx_graph_t* g, const int32_t* age_host, int32_t
         dbuf<unsigned long long> teen;
         GMX_CHECK(teen.alloc((size_t) ((V + 63) / 64)));
         hipLaunchKernelGGL(pred_bitmap_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0, (const int32_t*) age.p, V, 0, 0, teen.p);
-        GMX_CHECK(count_by_bitmap(g->r_begin.p, g->r_node_idx.p, V, nullptr, teen.p, 0, cnt.p, nullptr));
+        GMX_CHECK(count_by_bitmap(g->r_begin.p, g->r_node_idx.p, V, g->E, nullptr, teen.p, 0, cnt.p, nullptr));
         GMX_HIP(hipDeviceSynchronize());   // (teen is released at the end of this block)
     } else {                // forward CSR only: one increment per out-edge of a teen (integer atomics: same counts)
         GMX_CHECK(expand_selected<0>(g, age.p, 0, 0, cnt.p, nullptr));
@@ -2142,7 +2286,7 @@ extern "C" int gmx_conduct(gmx_graph_t* g, const int32_t* member_host, int32_t n
             dbuf<unsigned long long> mem_bm;
             GMX_CHECK(mem_bm.alloc((size_t) ((V + 63) / 64)));
             hipLaunchKernelGGL(pred_bitmap_kernel, dim3(grid_for(V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0, (const int32_t*) member.p, V, 1, num, mem_bm.p);
-            GMX_CHECK(count_by_bitmap(g->begin.p, g->node_idx.p, V, mem_bm.p, mem_bm.p, 1, nullptr, acc.p + 4));
+            GMX_CHECK(count_by_bitmap(g->begin.p, g->node_idx.p, V, g->E, mem_bm.p, mem_bm.p, 1, nullptr, acc.p + 4));
             GMX_HIP(hipDeviceSynchronize());
         }
         GMX_HIP(hipEventRecord(ev[1], 0));
