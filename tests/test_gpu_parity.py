@@ -1047,6 +1047,33 @@ def test_avg_teen_cnt_and_conduct(gmx, golden):
     g.free()
 
 
+@pytest.mark.parametrize("per_row", [False, True])
+def test_neighbour_counts_flat_and_per_row(gmx, per_row, monkeypatch):
+    """avg_teen_cnt (in-neighbours, reverse CSR) and conduct (out-neighbours of the members) through the flat merge-path
+    count and through round 2's one-row-per-lane count: rows cut by workgroup ranges (a star's hub: thousands of slots),
+    runs of empty rows, the last rows of the graph, against the oracle."""
+    if per_row:
+        monkeypatch.setenv("GMX_ROWCNT_PER_ROW", "1")
+    rng = np.random.default_rng(9)
+    n = 5000
+    star_src = np.concatenate([np.zeros(n - 1, np.int32), np.arange(1, n, dtype=np.int32)])
+    star_dst = np.concatenate([np.arange(1, n, dtype=np.int32), np.zeros(n - 1, np.int32)])
+    graphs = [po.rmat_graph(14, permute=False), po.rmat_graph(17, permute=True),
+              po.graph_from_edges(n, star_src, star_dst),                                         # hub rows of 4999 slots
+              po.graph_from_edges(9000, np.array([8999, 8999, 3], np.int32), np.array([0, 8998, 8999], np.int32))]   # almost only empty rows
+    for og in graphs:
+        g = gmx.Graph.upload(og.begin, og.node_idx, og.r_begin, og.r_node_idx)
+        for age in (rng.integers(0, 40, og.N).astype(np.int32), np.full(og.N, 15, np.int32)):
+            avg, cnt, _ = g.avg_teen_cnt(age, 5)
+            want_avg, want_cnt = po.avg_teen_cnt(og, age, 5)
+            assert np.array_equal(cnt, want_cnt)
+            assert np.float32(avg).tobytes() == np.float32(want_avg).tobytes()
+        member = rng.integers(0, 3, og.N).astype(np.int32)
+        for num in (0, 2, 5):
+            assert np.float32(g.conduct(member, num)[0]).tobytes() == np.float32(po.conduct(og, member, num)).tobytes()
+        g.free()
+
+
 def test_reverse_edge_map(gmx, golden):
     """gmx_graph_reverse_edge_map = gm_graph's e_rev2idx: a one-to-one map from reverse slots to forward slots
     with swapped endpoints, copies of a repeated edge in order (what make_reverse_edges leaves after the sort)."""
