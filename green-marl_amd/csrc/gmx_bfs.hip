@@ -1638,7 +1638,7 @@ __device__ __forceinline__ void bfs_append_big(bool is_big, int32_t v, int lane,
 // level `level` = order[lo, hi); begin / idx: the reverse CSR for DIR = -1, the forward CSR for DIR = +1
 template <class Visit>
 __global__ void __launch_bounds__(BFS_THREADS)
-bfs_visit_kernel(const int32_t* __restrict__ order, int64_t lo, int64_t hi, int32_t level, const int32_t* __restrict__ dist,
+bfs_visit_kernel(const int32_t* __restrict__ order, int64_t lo, int64_t hi, const uint32_t* __restrict__ nbr_level_bm,
                  const int32_t* __restrict__ begin, const int32_t* __restrict__ idx, int32_t skip, Visit vis,
                  int32_t* __restrict__ big_list, unsigned int* __restrict__ big_count) {
     const int lane = threadIdx.x & 63;
@@ -1657,7 +1657,7 @@ bfs_visit_kernel(const int32_t* __restrict__ order, int64_t lo, int64_t hi, int3
             float S = 0.0f;
             for (int32_t e = rb; e < rb + deg; e++) {
                 const int32_t w = idx[e];
-                if (dist[w] != level + Visit::DIR) continue;
+                if (!((nbr_level_bm[w >> 5] >> (w & 31)) & 1u)) continue;   // (w is not one level up / down)
                 S = S + vis.term(pv, w);
             }
             vis.finish(v, S);
@@ -1669,7 +1669,7 @@ bfs_visit_kernel(const int32_t* __restrict__ order, int64_t lo, int64_t hi, int3
 // the long rows of the level, one wave per row (any wave takes any row: a level's hubs run side by side)
 template <class Visit>
 __global__ void __launch_bounds__(BFS_THREADS)
-bfs_visit_big_kernel(const int32_t* __restrict__ big_list, const unsigned int* __restrict__ big_count, int32_t level, const int32_t* __restrict__ dist,
+bfs_visit_big_kernel(const int32_t* __restrict__ big_list, const unsigned int* __restrict__ big_count, const uint32_t* __restrict__ nbr_level_bm,
                      const int32_t* __restrict__ begin, const int32_t* __restrict__ idx, Visit vis) {
     const int lane = threadIdx.x & 63;
     const unsigned int n = *big_count, nwaves = gridDim.x * (blockDim.x >> 6);
@@ -1683,7 +1683,7 @@ bfs_visit_big_kernel(const int32_t* __restrict__ big_list, const unsigned int* _
             float term = 0.0f;
             if (e < degb) {
                 const int32_t w = idx[rbb + e];
-                pass = dist[w] == level + Visit::DIR;
+                pass = (nbr_level_bm[w >> 5] >> (w & 31)) & 1u;
                 if (pass) term = vis.term(pv, w);
             }
             S = bfs_ordered_add(S, term, __ballot(pass));
@@ -1700,10 +1700,16 @@ static int bfs_visit_level(gmx_graph* g, gmx_bfs* b, const int32_t* order, int64
     const int32_t* begin = Visit::DIR < 0 ? g->r_begin.p : g->begin.p;
     const int32_t* idx = Visit::DIR < 0 ? g->r_node_idx.p : g->node_idx.p;
     GMX_HIP(hipMemsetAsync(big_count, 0, sizeof(unsigned int), 0));
-    hipLaunchKernelGGL((bfs_visit_kernel<Visit>), dim3(grid_for(hi - lo)), dim3(BFS_THREADS), 0, 0, order, lo, hi, level, (const int32_t*) b->dist.p,
+    // "w is one level up / down" as a bitmap of that level (V / 8 bytes: it stays in the L2s) instead of a gather from level[]
+    // per slot -- a 64-byte line for four bytes, for every slot of every row, where only the slots that pass go on to gather
+    // sigma / delta (RMAT-24, the hub and four more seeds: 120 -> 104 ms).  The traversal's bitmaps are idle during the sweeps.
+    const uint32_t* nbr_bm = (const uint32_t*) b->bm[0].p;
+    hipLaunchKernelGGL(bfs_level_bitmap_kernel, dim3(grid_for(b->V, BFS_THREADS, 256 * 16)), dim3(BFS_THREADS), 0, 0, (const int32_t*) b->dist.p, b->V,
+                       level + Visit::DIR, b->bm[0].p);
+    hipLaunchKernelGGL((bfs_visit_kernel<Visit>), dim3(grid_for(hi - lo)), dim3(BFS_THREADS), 0, 0, order, lo, hi, nbr_bm,
                        begin, idx, skip, vis, big_list, big_count);
     hipLaunchKernelGGL((bfs_visit_big_kernel<Visit>), dim3(grid_for(hi - lo, 4, 1024)), dim3(BFS_THREADS), 0, 0, (const int32_t*) big_list,
-                       (const unsigned int*) big_count, level, (const int32_t*) b->dist.p, begin, idx, vis);
+                       (const unsigned int*) big_count, nbr_bm, begin, idx, vis);
     return GMX_OK;
 }
 
