@@ -148,7 +148,7 @@ def extras(gmx, graph26, scale):
         "ms": st["kernel_ms"], "levels": st["iterations"], "vertices_reached": st["vertices_reached"],
         "edges_reached": st["edges_reached"], "edges_examined": st["edges_examined"],
         "gteps": st["edges_reached"] / t / 1e9,
-        "first_call_wall_ms": walls[0], "warm_call_wall_ms": sorted(walls[1:])[1],
+        "first_call_wall_ms": walls[0], "warm_call_wall_ms": sorted(walls[1:])[1], "download_ms": st["d2h_ms"],
         "roofline_frac": (8 * st["edges_reached"] + 12 * st["vertices_reached"]) / t / 1e9 / HBM_PEAK_GBS,
         "note": "BASELINE configs[2]; ms = median of 3 warm traversals (device time of the traversal); the wall-clock figures are whole "
                 "gmx_hop_dist calls incl. the 256 MB dist[] download, the first one also the per-graph bottom-up hint and traversal "
