@@ -110,6 +110,20 @@ def extras(gmx, graph26, scale):
                      "download_ms": st["d2h_ms"],
                      "note": "gmx_pagerank_f64(e=0.001, d=0.85, max=100) wall clock: first call builds and caches the plan, "
                              "the second reuses it; both include the iterations and the copy of rank[] to the host"}
+    # the SURVEY 8f rank 3-4 apps on the same RMAT-24 (device time of the second call; inputs as the reference's drivers draw
+    # them in spirit: random edge lengths 1..100, random ages 0..99, four random groups, the top hub and four more seeds)
+    rng = np.random.default_rng(1)
+    hub = int(np.argmax(np.diff(g24.download(reverse=False)[0])))
+    length, age, member = rng.integers(1, 101, g24.E).astype(np.int32), rng.integers(0, 100, g24.V).astype(np.int32), rng.integers(0, 4, g24.V).astype(np.int32)
+    apps = {}
+    for _ in range(2):
+        apps["sssp_ms"] = g24.sssp(length, hub)[1]["kernel_ms"]
+        apps["avg_teen_cnt_ms"] = g24.avg_teen_cnt(age, 5)[2]["kernel_ms"]
+        apps["conduct_ms"] = g24.conduct(member, 1)[1]["kernel_ms"]
+        apps["bc_5_seeds_ms"] = g24.bc(np.array([hub, 1, 2, 3, 4], np.int32))[1]["kernel_ms"]
+    del length, age, member
+    out["apps_rmat24"] = dict(apps, note="sssp from the top hub, avg_teen_cnt(K=5), conduct(group 1), comp_BC(hub + 4 seeds): device time, "
+                                           "results checked against the oracle in tests/ (not here)")
     # triangle counting on the symmetrised simple version of the same RMAT-24
     gs = g24.symmetrize()
     g24.free()
