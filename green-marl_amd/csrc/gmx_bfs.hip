@@ -1614,6 +1614,7 @@ static int bfs_run(gmx_bfs* b, gmx_node_t root) {
 // and the passing terms added in slot order through v_readlane (hub rows of 10^5 slots were one lane's dependent-load
 // chain in round 2: comp_BC on RMAT-24, five seeds, 1.69 s -> 0.04 s).
 #define BFS_VISIT_SMALL 32
+#define BFS_BIG_CHUNKS 8   // 64-slot chunks of a long row in flight per step
 
 // S = S + term for every set bit of `pass`, ascending lane = ascending slot (wave-uniform result)
 __device__ __forceinline__ float bfs_ordered_add(float S, float term, unsigned long long pass) {
@@ -1677,16 +1678,29 @@ bfs_visit_big_kernel(const int32_t* __restrict__ big_list, const unsigned int* _
         const int32_t vb = big_list[k], rbb = begin[vb], degb = begin[vb + 1] - rbb;
         const float pv = vis.prep(vb);
         float S = 0.0f;
-        for (int32_t c = 0; c < degb; c += 64) {
-            const int32_t e = c + lane;
-            bool pass = false;
-            float term = 0.0f;
-            if (e < degb) {
-                const int32_t w = idx[rbb + e];
-                pass = (nbr_level_bm[w >> 5] >> (w & 31)) & 1u;
-                if (pass) term = vis.term(pv, w);
+        // BFS_BIG_CHUNKS x 64 slots per step: the slots, then their level bits, then the passing slots' terms are each
+        // requested for all chunks of the step before the first is used -- the adds stay one chain in slot order, but a hub's
+        // row (10^5 slots, one wave) is no longer 1600 round trips of three dependent loads each (3.2 ms per level, the
+        // level's whole time)
+        for (int32_t c = 0; c < degb; c += 64 * BFS_BIG_CHUNKS) {
+            int32_t w[BFS_BIG_CHUNKS];
+            uint32_t bits[BFS_BIG_CHUNKS];
+            bool pass[BFS_BIG_CHUNKS];
+            float term[BFS_BIG_CHUNKS];
+#pragma unroll
+            for (int k = 0; k < BFS_BIG_CHUNKS; k++) {
+                const int32_t e = c + 64 * k + lane;
+                w[k] = idx[rbb + (e < degb ? e : degb - 1)];
             }
-            S = bfs_ordered_add(S, term, __ballot(pass));
+#pragma unroll
+            for (int k = 0; k < BFS_BIG_CHUNKS; k++) bits[k] = nbr_level_bm[w[k] >> 5];
+#pragma unroll
+            for (int k = 0; k < BFS_BIG_CHUNKS; k++) {
+                pass[k] = c + 64 * k + lane < degb && ((bits[k] >> (w[k] & 31)) & 1u);
+                term[k] = pass[k] ? vis.term(pv, w[k]) : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < BFS_BIG_CHUNKS; k++) S = bfs_ordered_add(S, term[k], __ballot(pass[k]));
         }
         if (lane == 0) vis.finish(vb, S);
     }
@@ -1726,25 +1740,35 @@ static int bfs_sweep(gmx_graph* g, gmx_bfs* b, const bfs_order& ord, int32_t ski
 }
 
 // comp_BC's two visits (apps/src/bc.gm:16-29)
+// sigma and delta of a vertex side by side (x = sigma, y = delta): the reverse visit needs both of every down-neighbour that
+// passes, and one 8-byte gather is one line request where two 4-byte gathers from two arrays are two
 struct bc_visit_fw {   // v.sigma = Sum(w: v.UpNbrs){ w.sigma }
     static constexpr int DIR = -1;
-    float* sigma;
+    float2* sd;
     __device__ float prep(int32_t) const { return 0.0f; }
-    __device__ float term(float, int32_t w) const { return sigma[w]; }
-    __device__ void finish(int32_t v, float S) const { sigma[v] = S; }
+    __device__ float term(float, int32_t w) const { return sd[w].x; }
+    __device__ void finish(int32_t v, float S) const { sd[v].x = S; }
 };
 struct bc_visit_rv {   // v.delta = Sum(w: v.DownNbrs){ v.sigma / w.sigma * (1 + w.delta) };  v.BC += v.delta
     static constexpr int DIR = +1;
-    const float* sigma;
-    float* delta;
+    float2* sd;
     float* bc;
-    __device__ float prep(int32_t v) const { return sigma[v]; }
-    __device__ float term(float sv, int32_t w) const { return sv / sigma[w] * (1 + delta[w]); }
+    __device__ float prep(int32_t v) const { return sd[v].x; }
+    __device__ float term(float sv, int32_t w) const {
+        const float2 q = sd[w];
+        return sv / q.x * (1 + q.y);
+    }
     __device__ void finish(int32_t v, float S) const {
-        delta[v] = S;
+        sd[v].y = S;
         bc[v] = bc[v] + S;
     }
 };
+
+__global__ void fill_sigma_kernel(float2* __restrict__ sd, int64_t n, int64_t one_at) {   // G.sigma = 0; s.sigma = 1 (delta stays)
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) sd[i].x = i == one_at ? 1.0f : 0.0f;
+}
 
 __global__ void fill_f32_kernel(float* __restrict__ p, int64_t n, float v, int64_t one_at, float one_v) {
     int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -1761,13 +1785,14 @@ extern "C" int gmx_bc(gmx_graph_t* g, const gmx_node_t* seeds, int32_t nseeds, i
     for (int32_t i = 0; i < nseeds; i++) GMX_REQUIRE(seeds[i] >= 0 && seeds[i] < V, "seed %d out of range", seeds[i]);
     if (!g->bfs_cache) GMX_CHECK(gmx_bfs_create(g, 0, 1, &g->bfs_cache));
     gmx_bfs* b = g->bfs_cache;
-    dbuf<float> sigma, delta, bc;
+    dbuf<float2> sd;
+    dbuf<float> bc;
     dbuf<int32_t> big_list;
     dbuf<unsigned int> big_count;
     GMX_CHECK(big_list.alloc((size_t) V));
     GMX_CHECK(big_count.alloc(1));
-    GMX_CHECK(sigma.alloc((size_t) V));
-    GMX_CHECK(delta.alloc((size_t) V));
+    GMX_CHECK(sd.alloc((size_t) V));
+    GMX_HIP(hipMemsetAsync(sd.p, 0, sizeof(float2) * (size_t) V, 0));   // (delta of a vertex no visit has written is never read; zero all the same)
     GMX_CHECK(bc.alloc((size_t) V));
     bfs_order ord;
     ev_guard e0, e1;
@@ -1778,12 +1803,12 @@ extern "C" int gmx_bc(gmx_graph_t* g, const gmx_node_t* seeds, int32_t nseeds, i
     int64_t reached = 0;
     for (int32_t si = 0; si < nseeds; si++) {   // For (s: Seeds.Items): sequential, as emitted
         const gmx_node_t s = seeds[si];
-        hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, sigma.p, V, 0.0f, (int64_t) s, 1.0f);   // G.sigma = 0; s.sigma = 1
+        hipLaunchKernelGGL(fill_sigma_kernel, dim3(grid_for(V)), dim3(BFS_THREADS), 0, 0, sd.p, V, (int64_t) s);   // G.sigma = 0; s.sigma = 1
         GMX_CHECK(bfs_run(b, s));
         GMX_CHECK(bfs_make_order(b, &ord));
         reached += ord.h_off[(size_t) ord.levels];
         const int32_t skip = skip_root ? s : -1;
-        GMX_CHECK(bfs_sweep(g, b, ord, skip, bc_visit_fw{sigma.p}, bc_visit_rv{sigma.p, delta.p, bc.p}, big_list.p, big_count.p));
+        GMX_CHECK(bfs_sweep(g, b, ord, skip, bc_visit_fw{sd.p}, bc_visit_rv{sd.p, bc.p}, big_list.p, big_count.p));
     }
     GMX_HIP(hipEventRecord(e1.e, 0));
     GMX_HIP(hipEventSynchronize(e1.e));
