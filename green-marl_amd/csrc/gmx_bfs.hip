@@ -1614,9 +1614,19 @@ static int bfs_run(gmx_bfs* b, gmx_node_t root) {
 // and the passing terms added in slot order through v_readlane (hub rows of 10^5 slots were one lane's dependent-load
 // chain in round 2: comp_BC on RMAT-24, five seeds, 1.69 s -> 0.04 s).
 #define BFS_VISIT_SMALL 32
+#define BFS_DENSE_PASS 16  // passing lanes of a chunk from which all 64 lanes are added in order (the others as +0.0f)
 #define BFS_BIG_CHUNKS 8   // 64-slot chunks of a long row in flight per step
 
 // S = S + term for every set bit of `pass`, ascending lane = ascending slot (wave-uniform result)
+// the same sum when most lanes pass: all 64 lanes in order, the others contributing +0.0f -- no loop over the mask's bits, the
+// lane indices are constants.  x + (+0.0f) == x bit for bit unless x is -0.0f, so this is for visits whose terms are never
+// negative (Visit::NONNEG): S then starts at +0.0f and stays non-negative.
+__device__ __forceinline__ float bfs_ordered_add_dense(float S, float term, bool pass) {
+    const int t = __builtin_bit_cast(int, pass ? term : 0.0f);
+#pragma unroll
+    for (int j = 0; j < 64; j++) S = S + __builtin_bit_cast(float, __builtin_amdgcn_readlane(t, j));
+    return S;
+}
 __device__ __forceinline__ float bfs_ordered_add(float S, float term, unsigned long long pass) {
     while (pass) {
         const int j = __builtin_ctzll(pass);
@@ -1700,7 +1710,11 @@ bfs_visit_big_kernel(const int32_t* __restrict__ big_list, const unsigned int* _
                 term[k] = pass[k] ? vis.term(pv, w[k]) : 0.0f;
             }
 #pragma unroll
-            for (int k = 0; k < BFS_BIG_CHUNKS; k++) S = bfs_ordered_add(S, term[k], __ballot(pass[k]));
+            for (int k = 0; k < BFS_BIG_CHUNKS; k++) {
+                const unsigned long long m = __ballot(pass[k]);
+                if (Visit::NONNEG && __builtin_popcountll(m) > BFS_DENSE_PASS) S = bfs_ordered_add_dense(S, term[k], pass[k]);
+                else S = bfs_ordered_add(S, term[k], m);
+            }
         }
         if (lane == 0) vis.finish(vb, S);
     }
@@ -1744,6 +1758,7 @@ static int bfs_sweep(gmx_graph* g, gmx_bfs* b, const bfs_order& ord, int32_t ski
 // passes, and one 8-byte gather is one line request where two 4-byte gathers from two arrays are two
 struct bc_visit_fw {   // v.sigma = Sum(w: v.UpNbrs){ w.sigma }
     static constexpr int DIR = -1;
+    static constexpr bool NONNEG = true;   // path counts
     float2* sd;
     __device__ float prep(int32_t) const { return 0.0f; }
     __device__ float term(float, int32_t w) const { return sd[w].x; }
@@ -1751,6 +1766,7 @@ struct bc_visit_fw {   // v.sigma = Sum(w: v.UpNbrs){ w.sigma }
 };
 struct bc_visit_rv {   // v.delta = Sum(w: v.DownNbrs){ v.sigma / w.sigma * (1 + w.delta) };  v.BC += v.delta
     static constexpr int DIR = +1;
+    static constexpr bool NONNEG = true;   // sigma > 0 on reached vertices, delta >= 0
     float2* sd;
     float* bc;
     __device__ float prep(int32_t v) const { return sd[v].x; }
