@@ -174,6 +174,22 @@ bfs_degree_scan_small_kernel(const int32_t* __restrict__ begin, const int32_t* _
     }
 }
 
+// rows consumed at the merge-path diagonals k * BFS_ITEMS, k = 0 .. nb, of (n frontier rows, m edges): one thread per
+// diagonal.  Searched inside the level kernels -- two threads, log2(n) dependent loads over off[], the other 254 at the barrier
+// -- it was most of a workgroup's time once n is in the millions (an sssp round at RMAT-24: ~20 of ~25 us per workgroup).
+__global__ void bfs_merge_split_kernel(const int64_t* __restrict__ off, int64_t n, int64_t m, int64_t nb, int64_t* __restrict__ split) {
+    const int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > nb) return;
+    int64_t dk = k * BFS_ITEMS;
+    if (dk > n + m) dk = n + m;
+    int64_t lo = dk > m ? dk - m : 0, hi = dk < n ? dk : n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (off[mid + 1] <= dk - mid - 1) lo = mid + 1; else hi = mid;
+    }
+    split[k] = lo;
+}
+
 // off[0..n] = exclusive prefix sums of the frontier degrees (off[n] = frontier edges).
 // Block k handles path items [k*BFS_ITEMS, (k+1)*BFS_ITEMS) of the merged (vertex ends, edges) sequence.
 __global__ void __launch_bounds__(BFS_THREADS)
@@ -1325,29 +1341,19 @@ __global__ void __launch_bounds__(BFS_THREADS)
 sssp_relax_kernel(const int32_t* __restrict__ begin, const int32_t* __restrict__ node_idx, const int32_t* __restrict__ len,
                   const int32_t* __restrict__ cur_q, int64_t n, const int64_t* __restrict__ off, int64_t m,
                   int32_t round, int32_t* __restrict__ dist, int32_t* __restrict__ stamp, int32_t* __restrict__ next_q,
-                  bfs_counters* __restrict__ ctr) {
+                  bfs_counters* __restrict__ ctr, const int64_t* __restrict__ split) {
     __shared__ int64_t s_off[BFS_ITEMS + 2];
     __shared__ int32_t s_row[BFS_ITEMS + 2];
     __shared__ int32_t s_dist[BFS_ITEMS + 2];
-    __shared__ int64_t s_split[2][2];
     __shared__ int32_t s_win[BFS_ITEMS];   // (one queue-tail claim per workgroup, as in bfs_topdown_kernel)
     __shared__ unsigned int s_nwin;
     __shared__ unsigned long long s_base;
     const int tid = threadIdx.x;
     if (tid == 0) s_nwin = 0;
-    if (tid < 2) {
-        int64_t dk = ((int64_t) blockIdx.x + tid) * BFS_ITEMS;
-        if (dk > n + m) dk = n + m;
-        int64_t lo = dk > m ? dk - m : 0, hi = dk < n ? dk : n;
-        while (lo < hi) {
-            int64_t mid = (lo + hi) >> 1;
-            if (off[mid + 1] <= dk - mid - 1) lo = mid + 1; else hi = mid;
-        }
-        s_split[tid][0] = lo;
-        s_split[tid][1] = dk - lo;
-    }
-    __syncthreads();
-    const int64_t v0 = s_split[0][0], e0 = s_split[0][1], v1 = s_split[1][0], e1 = s_split[1][1];
+    // merge-path split of the diagonals k * ITEMS and (k + 1) * ITEMS (bfs_merge_split_kernel): (rows consumed, edges consumed)
+    int64_t d0 = (int64_t) blockIdx.x * BFS_ITEMS, d1 = d0 + BFS_ITEMS;
+    if (d1 > n + m) d1 = n + m;
+    const int64_t v0 = split[blockIdx.x], v1 = split[blockIdx.x + 1], e0 = d0 - v0, e1 = d1 - v1;
     const int nv = (int) (v1 - v0) + 1;
     for (int i = tid; i < nv; i += BFS_THREADS) {
         const int64_t vi = v0 + i;
@@ -1429,10 +1435,11 @@ extern "C" int gmx_sssp(gmx_graph_t* g, gmx_node_t root, const int32_t* len_host
     if (V == 0) return GMX_OK;
     const bool root_ok = root >= 0 && root < V;
     dbuf<int32_t> dist, stamp, q0, q1, deg, len;
-    dbuf<int64_t> off;
+    dbuf<int64_t> off, split;
     dbuf<bfs_counters> ctr;
     dbuf<char> scan_tmp;
     size_t scan_bytes = 0;
+    GMX_CHECK(split.alloc((size_t) ((V + g->E) / BFS_ITEMS + 3)));   // one entry per merge-path diagonal of a round
     GMX_CHECK(dist.alloc((size_t) V));
     GMX_CHECK(stamp.alloc((size_t) V));
     GMX_CHECK(q0.alloc((size_t) V));
@@ -1489,9 +1496,12 @@ extern "C" int gmx_sssp(gmx_graph_t* g, gmx_node_t root, const int32_t* len_host
         GMX_HIP(hipStreamSynchronize(0));
         const int64_t m_f = *h_mf;
         const int64_t nb = (cur_count + m_f + BFS_ITEMS - 1) / BFS_ITEMS;
-        if (nb > 0)
+        if (nb > 0) {
+            hipLaunchKernelGGL(bfs_merge_split_kernel, dim3((unsigned) ((nb + 1 + BFS_THREADS - 1) / BFS_THREADS)), dim3(BFS_THREADS), 0, 0,
+                               (const int64_t*) off.p, cur_count, m_f, nb, split.p);
             hipLaunchKernelGGL(sssp_relax_kernel, dim3((unsigned) nb), dim3(BFS_THREADS), 0, 0, g->begin.p, g->node_idx.p,
-                               len_dev, cur_q, cur_count, off.p, m_f, round, dist.p, stamp.p, next_q, ctr.p);
+                               len_dev, cur_q, cur_count, off.p, m_f, round, dist.p, stamp.p, next_q, ctr.p, (const int64_t*) split.p);
+        }
         GMX_HIP(hipGetLastError());
         GMX_HIP(hipMemcpyAsync(h_ctr, ctr.p, sizeof(bfs_counters), hipMemcpyDeviceToHost, 0));
         GMX_HIP(hipStreamSynchronize(0));
